@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE compiled from its own sources (oracle/_ref).
+
+Run in the build container only (needs /root/reference and `make -C oracle ref`):
+
+    python tests/golden/make_golden.py            # per-layer KATs + full-network tensors
+
+The reference ships no golden vectors, so these files pin parity:
+each holds inputs and the outputs the reference's own YOLO2_FPGA / yolov2_hls_ps produced
+for them.  Only data is stored here, never reference source.
+"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "yolo-fpga-accelerator_amd"))
+
+import orclib  # noqa: E402
+from yolo2_amd import synth  # noqa: E402
+
+REF_CFG = "/root/reference/config/yolov2.cfg"
+
+
+def conv_cases():
+    """(name, C, N, K, stride, W, H, leaky, Qw, Qa_in, Qa_out, Qb, x_amp, w_amp, special)"""
+    return [
+        ("c3_first_layer_like", 3, 32, 3, 1, 26, 26, 1, 14, 14, 9, 12, 16384, 6000, None),
+        ("partial_tm_tn_ragged", 7, 45, 3, 1, 17, 19, 1, 14, 9, 9, 12, 3000, 3000, None),
+        ("k1_linear", 64, 40, 1, 1, 13, 13, 0, 14, 9, 9, 12, 3000, 3000, None),
+        ("k1_leaky_425", 16, 425, 1, 1, 13, 13, 1, 13, 9, 10, 11, 3000, 3000, None),
+        ("saturation_heavy", 8, 33, 3, 1, 14, 14, 1, 14, 9, 9, 12, 32768, 32768, None),
+        ("left_shift_out", 5, 9, 3, 1, 20, 15, 1, 4, 9, 14, 12, 3000, 3000, None),
+        ("left_shift_bias", 6, 6, 1, 1, 9, 9, 1, 14, 9, 9, 3, 3000, 3000, None),
+        ("zero_shift", 4, 8, 3, 1, 13, 13, 1, 3, 6, 9, 9, 40, 40, None),
+        ("all_min_overflow32", 4, 4, 3, 1, 5, 5, 0, 14, 9, 9, 12, 0, 0, "allmin"),
+        ("mixed_extremes", 8, 8, 3, 1, 13, 13, 1, 15, 10, 9, 12, 0, 0, "extremes"),
+        ("stride2", 6, 10, 3, 2, 16, 16, 1, 14, 9, 9, 12, 3000, 3000, None),
+        ("mid_52", 16, 32, 3, 1, 52, 52, 1, 14, 9, 9, 12, 600, 1500, None),
+        ("single_pixel", 12, 5, 1, 1, 1, 1, 1, 14, 9, 9, 12, 3000, 3000, None),
+    ]
+
+
+def make_conv_inputs(case, rng):
+    name, C, N, K, stride, W, H, leaky, Qw, Qai, Qao, Qb, xa, wa, special = case
+    W8 = orclib.w8(W)
+    x = np.zeros((C, H, W8), dtype=np.int16)
+    if special == "allmin":
+        x[:, :, :W] = -32768
+        w = np.full((N, C, K, K), -32768, dtype=np.int16)
+        b = np.full(N, 32767, dtype=np.int16)
+    elif special == "extremes":
+        x[:, :, :W] = rng.choice(np.array([-32768, 32767, -1, 0, 1], dtype=np.int16), (C, H, W))
+        w = rng.choice(np.array([-32768, 32767, -1, 0, 1], dtype=np.int16), (N, C, K, K))
+        b = rng.choice(np.array([-32768, 32767, 0], dtype=np.int16), N)
+    else:
+        x[:, :, :W] = rng.integers(-xa, xa, (C, H, W)).clip(-32768, 32767)
+        w = rng.integers(-wa, wa, (N, C, K, K)).clip(-32768, 32767).astype(np.int16)
+        b = rng.integers(-20000, 20000, N).astype(np.int16)
+    return x, w, b
+
+
+def gen_kats():
+    rng = np.random.default_rng(20260327)
+    out = {}
+    names = []
+    for case in conv_cases():
+        name, C, N, K, stride, W, H, leaky, Qw, Qai, Qao, Qb, xa, wa, special = case
+        pad = 1 if K == 3 else 0
+        x, w, b = make_conv_inputs(case, rng)
+        wr = synth.reorg_weights(w, C, N, K)
+        y = orclib.ref_conv(x, wr, b, C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb, fill=0)
+        out[f"conv_i16/{name}/x"] = x
+        out[f"conv_i16/{name}/w_reorg"] = wr
+        out[f"conv_i16/{name}/bias"] = b
+        out[f"conv_i16/{name}/params"] = np.array([C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb], dtype=np.int32)
+        out[f"conv_i16/{name}/y"] = y
+        names.append(name)
+        print("conv_i16", name, y.shape, "saturated:", int((np.abs(y.astype(np.int32)) >= 32767).sum()))
+    out["conv_i16/names"] = np.array(names)
+
+    fnames = []
+    for (name, C, N, K, W, H, leaky) in [("c3", 3, 32, 3, 26, 26, 1), ("ragged", 7, 45, 3, 17, 19, 1),
+                                         ("k1_linear", 64, 40, 1, 13, 13, 0), ("mid_52", 16, 32, 3, 52, 52, 1)]:
+        pad = 1 if K == 3 else 0
+        x = np.zeros((C, H, orclib.w8(W)), dtype=np.float32)
+        x[:, :, :W] = rng.standard_normal((C, H, W)).astype(np.float32)
+        w = (rng.standard_normal((N, C, K, K)) * np.sqrt(2.0 / (C * K * K))).astype(np.float32)
+        b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+        wr = synth.reorg_weights(w, C, N, K)
+        y = orclib.ref_conv(x, wr, b, C, N, K, 1, W, H, pad, leaky)
+        out[f"conv_f32/{name}/x"] = x
+        out[f"conv_f32/{name}/w_reorg"] = wr
+        out[f"conv_f32/{name}/bias"] = b
+        out[f"conv_f32/{name}/params"] = np.array([C, N, K, 1, W, H, pad, leaky], dtype=np.int32)
+        out[f"conv_f32/{name}/y"] = y
+        fnames.append(name)
+        print("conv_f32", name, y.shape)
+    out["conv_f32/names"] = np.array(fnames)
+
+    # maxpool, with -32768 inputs and ragged channel count
+    for C, W, H in [(5, 14, 10), (32, 26, 26)]:
+        x = np.zeros((C, H, orclib.w8(W)), dtype=np.int16)
+        x[:, :, :W] = rng.integers(-32768, 32767, (C, H, W))
+        x[0, :2, :2] = -32768
+        out[f"pool_i16/{C}x{H}x{W}/x"] = x
+        out[f"pool_i16/{C}x{H}x{W}/y"] = orclib.ref_maxpool(x, C, W, H)
+        xf = np.zeros((C, H, orclib.w8(W)), dtype=np.float32)
+        xf[:, :, :W] = rng.standard_normal((C, H, W)).astype(np.float32) * 5
+        xf[0, :2, :2] = -2.0e6   # below the reference's -1024*1024 floor: the floor wins
+        out[f"pool_f32/{C}x{H}x{W}/x"] = xf
+        out[f"pool_f32/{C}x{H}x{W}/y"] = orclib.ref_maxpool(xf, C, W, H)
+    np.savez_compressed(os.path.join(HERE, "kat_layers.npz"), **out)
+    print("wrote kat_layers.npz")
+
+
+Q_SETS = {
+    # the benchmark configuration: Qw=14, Qb=12, act_q=[14, 9 x 23]
+    "std": dict(),
+    # varied tables: exercises conv-ordinal Q indexing, the route-28 alignment shift
+    # (act_q[21] > act_q[20] -> reorg branch >>2, layer 29 Qa_in = 8) and Qb != 12
+    "varq": dict(weight_q=[14, 14, 13, 14, 15, 14, 14, 13, 14, 14, 15, 14, 14, 14, 13, 14, 14, 14, 15, 14, 14, 14, 13],
+                 bias_q=[12, 11, 12, 12, 13, 12, 12, 12, 10, 12, 12, 12, 12, 12, 12, 12, 12, 11, 12, 12, 12, 12, 9],
+                 act_q=[14, 9, 10, 9, 9, 10, 9, 9, 9, 8, 9, 9, 10, 9, 9, 9, 9, 9, 9, 9, 8, 10, 9, 9]),
+}
+
+
+def run_ref_fullnet(model, frame, int16):
+    """Runs the reference's own yolov2_hls_ps in a scratch cwd holding weights/*.bin."""
+    work = tempfile.mkdtemp(prefix="ref_fullnet_")
+    cwd = os.getcwd()
+    try:
+        model.write_files(os.path.join(work, "weights"), fp32=not int16, int16=int16)
+        os.chdir(work)
+        raw_path = os.path.join(work, "raw.txt")
+        os.environ["YOLO2_DUMP_REGION_RAW_CPU"] = raw_path
+        proc = np.zeros(425 * 169, dtype=np.float32)
+        n = orclib.ref(int16).ref_yolov2_hls_ps(REF_CFG.encode(), np.ascontiguousarray(frame), proc)
+        assert n == 425 * 169, n
+        raw = np.loadtxt(raw_path, dtype=np.float64)
+        assert raw.size == 425 * 169
+        return raw, proc
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def gen_fullnet():
+    out = {}
+    for qname, kw in Q_SETS.items():
+        model = synth.SynthModel(seed=1, **kw)
+        frame = synth.frames(seed=7, count=1)[0]
+        raw, proc = run_ref_fullnet(model, frame, int16=True)
+        # the raw dump is int16 * 2^-Q printed with %.9g: recover the integers exactly
+        # (final Q = last Qa_out; for both sets act_q[23])
+        qf = int(model.act_q[23])
+        ri = np.rint(raw * (1 << qf)).astype(np.int64)
+        # %.9g keeps 9 significant digits: far finer than the 2^-Q grid, so rint() is exact
+        assert np.all(np.abs(ri * 2.0 ** -qf - raw) <= 1e-7 * np.maximum(1.0, np.abs(raw))), "raw dump not on the int16 grid"
+        assert ri.min() >= -32768 and ri.max() <= 32767
+        out[f"i16/{qname}/region_raw_i16"] = ri.astype(np.int16)
+        out[f"i16/{qname}/region_proc_f32"] = proc
+        out[f"i16/{qname}/final_q"] = np.int32(qf)
+        print("fullnet int16", qname, "raw min/max", ri.min(), ri.max(), "nonzero", int((ri != 0).sum()))
+        if qname == "std":
+            rawf, procf = run_ref_fullnet(model, frame, int16=False)
+            out["f32/std/region_raw_f32"] = rawf.astype(np.float32)
+            out["f32/std/region_proc_f32"] = procf
+            print("fullnet fp32 raw min/max", rawf.min(), rawf.max())
+    out["meta/model_seed"] = np.int32(1)
+    out["meta/frame_seed"] = np.int32(7)
+    np.savez_compressed(os.path.join(HERE, "fullnet.npz"), **out)
+    print("wrote fullnet.npz")
+
+
+if __name__ == "__main__":
+    if not orclib.have_ref():
+        sys.exit("oracle/_ref is not built: run `make -C oracle ref` in the build container")
+    what = sys.argv[1:] or ["kats", "fullnet"]
+    if "kats" in what:
+        gen_kats()
+    if "fullnet" in what:
+        gen_fullnet()
