@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- YOLOv2 INT16 416x416 frames/sec on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the accelerator path (input quantise -> 23 conv + 5 maxpool + reorg ->
+region gather) over one batch of synthetic frames already resident in HBM.  One process per
+GPU; frames shard across ranks with no data-path collective (weak scaling: --batch frames per
+GPU); the only collective is the broadcast of the weight blobs at init (RCCL over xGMI).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "yolo-fpga-accelerator_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from yolo2_amd import dist as ydist  # noqa: E402
+from yolo2_amd import hipdrv, net, synth  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# integer VALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (same issue rate as the 157.3 TFLOP/s fp32 vector peak / 2)
+VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
+OPS_PER_STEP = {0: 5, 1: 4, 2: None}   # VALU instructions per requant step of each kernel form
+
+
+def conv_layer_bytes(l, batch):
+    """Algorithmic HBM bytes of one conv launch (layer-at-a-time model)."""
+    act = (l.c * l.h * l.w + l.n * l.out_h * l.out_w) * 2 * batch
+    wts = (l.n * l.c * l.size * l.size + l.n) * 2
+    return act + wts
+
+
+def cpu_baseline(model, frame, gpu_region):
+    """Times the CPU side on a bounded sample (ONE frame) and checks the GPU result against it.
+    Preferred: the reference itself, compiled from its own sources (oracle/_ref), driving every
+    conv and maxpool layer through its YOLO2_FPGA exactly as yolov2_hls_ps does, single thread
+    (the reference is not re-entrant).  Fallback: our C restatement (oracle/liboracle.so)."""
+    import orclib
+    out = {}
+    if orclib.have_ref():
+        x = np.zeros((3, 416, 416), dtype=np.int16)
+        orclib.oracle().orc_quantize_input(np.ascontiguousarray(frame), x.reshape(-1), x.size, int(model.act_q[0]))
+        wq, bq, aq = model.weight_q, model.bias_q, model.act_q
+        outs = {}
+        cur = x
+        t0 = time.perf_counter()
+        for l in net.LAYERS:
+            if l.type == net.CONV:
+                src = outs[16] if l.idx == 26 else (np.concatenate([outs[27], outs[24]]) if l.idx == 29 else cur)
+                cur = orclib.ref_conv(src, model.w_reorg[l.ord], model.bias[l.ord], l.c, l.n, l.size, 1, l.w, l.h,
+                                      l.pad, l.leaky, int(wq[l.ord]), int(aq[l.ord]), int(aq[l.ord + 1]), int(bq[l.ord]))
+                outs[l.idx] = cur
+            elif l.type == net.MAXPOOL:
+                cur = orclib.ref_maxpool(cur, l.c, l.w, l.h)
+                outs[l.idx] = cur
+            elif l.type == net.REORG:
+                o = np.zeros((256, 13, 16), dtype=np.int16)
+                orclib.oracle().orc_reorg_i16(np.ascontiguousarray(cur), o, 0)   # std Q set: no alignment shift
+                cur = o
+                outs[l.idx] = cur
+        dt = time.perf_counter() - t0
+        region = cur[:, :, :13].reshape(-1)
+        out = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "1 frame: 23 conv + 5 maxpool layers through the reference's own YOLO2_FPGA "
+                         "(oracle/_ref, built from the reference sources), single thread, weights in memory",
+               "seconds_per_frame": dt}
+    else:
+        orclib.oracle().orc_set_threads(1)
+        t0 = time.perf_counter()
+        region, _, _ = orclib.forward_i16(model, frame)
+        dt = time.perf_counter() - t0
+        out = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "1 frame through oracle/yolo2_oracle.c (bit-exact C restatement), single thread",
+               "seconds_per_frame": dt}
+    out["gpu_matches_cpu_bit_exact"] = bool(np.array_equal(np.asarray(region).reshape(-1), gpu_region.reshape(-1)))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (configs[2]: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    # ---- init: rank 0 builds the synthetic weight set; ONE broadcast puts it on every GPU
+    model = synth.SynthModel(seed=1) if rank == 0 else None
+    w, b, wq, bq, aq = ydist.broadcast_model(model, dev)
+    ctx = hipdrv.Yolo2Hip(local_rank)
+    ctx.load_weights_dev(w.data_ptr(), w.numel(), b.data_ptr(), b.numel(), wq, bq, aq)
+    del w, b
+    ctx.set_batch(B)
+
+    # ---- this rank's shard of the global synthetic batch, resident in HBM before timing
+    lo, hi = ydist.shard_range(B * world, rank, world)
+    frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
+    region = torch.empty((B, 425, 13, 13), dtype=torch.int16, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.run_batch_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)      # hipEvent pairs around every layer launch, on `stream`
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    layer_ms = ctx.layer_times_ms()
+    ctx.set_profiling(False)
+
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        paths = ctx.layer_paths()
+        # dominant kernel = the conv kernel instantiation with the largest total time
+        groups = {}
+        for l in net.CONVS:
+            info = ctx.conv_launch_info(l.ord)
+            key = (l.size, info["pixels_per_lane"], paths[l.ord])
+            g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "bytes": 0.0, "steps": 0, "layers": []})
+            g["ms"] += float(layer_ms[l.idx])
+            g["launches"] += 1
+            g["bytes"] += conv_layer_bytes(l, B)
+            g["steps"] += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B
+            g["layers"].append(l.idx)
+        key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        avg_ms = g["ms"] / g["launches"]
+        ach = (g["bytes"] / g["launches"]) / (avg_ms * 1e-3) / 1e9
+        kname = f"k_conv_i16<KS={key[0]},P={key[1]},MODE={key[2]}>"
+        conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
+        ops = OPS_PER_STEP.get(key[2])
+        valu = None
+        if ops:
+            lane_ops = g["steps"] * ops / (g["ms"] * 1e-3) / 1e12
+            valu = {"bound": "valu_int", "kernel": kname, "achieved": lane_ops, "peak": VALU_PEAK_TLANEOPS,
+                    "unit": "T lane-ops/s", "frac": lane_ops / VALU_PEAK_TLANEOPS,
+                    "note": f"{ops} VALU instructions per (4 channels x tap x output) requant step; "
+                            "the int16 path is integer-VALU bound, not HBM bound (SURVEY.md 8d)"}
+        result = {
+            "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"YOLOv2 INT16 416x416 batch={B} per GPU, bit-exact int16 conv/bias/leaky/maxpool/reorg path",
+                       "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded x{world}, weights broadcast once",
+                       "conv_paths": paths},
+            "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
+                         "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]},
+            "valu_roofline": valu,
+            "layer_ms": [round(float(x), 4) for x in layer_ms],
+            "conv_ms_per_step": conv_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            gpu_region0 = region[0].cpu().numpy()
+            result["cpu_baseline"] = cpu_baseline(model, frames[0].cpu().numpy(), gpu_region0)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/*
+ * yolo2_hip.h -- C ABI of the MI355X (gfx950) YOLOv2 accelerator library, libyolo2_hip.so.
+ *
+ * This is the drop-in boundary: it stands where the reference's AXI-Lite/udmabuf driver
+ * stands (linux_app/include/yolo2_accel_linux.h, linux_app/include/dma_buffer_manager.h)
+ * and where the host simulation calls YOLO2_FPGA (hls/models/yolov2/yolo2_accel.hpp:10-17).
+ * Plain C: pointers, sizes and ints only; no C++ exceptions cross it; every entry point
+ * returns one of the reference's status codes (linux_app/include/yolo2_config.h:146-151).
+ *
+ * "Physical address" in the reference == a device-accessible address here (uint64_t):
+ * either HBM from yolo2_hip_alloc(), or mapped pinned host memory from memory_allocate_*().
+ *
+ * Three tiers, innermost first:
+ *   1. driver + per-layer calls with the reference's exact argument lists and DRAM layouts
+ *      (feature maps [C][H][W8], weights in weights_reorg order) -- lets the reference's C
+ *      layer loop (linux_app/src/yolo2_inference.c:763-910) drive the GPU unchanged;
+ *   2. whole-network batched entry: weights resident in HBM, 28 layer kernels per batch
+ *      on one stream, one host sync per batch instead of one per layer;
+ *   3. helpers the callers on either side need (weight-file quirks, region gather).
+ */
+#ifndef YOLO2_HIP_H
+#define YOLO2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* linux_app/include/yolo2_config.h:146-151 */
+#define YOLO2_SUCCESS     0
+#define YOLO2_ERROR      -1
+#define YOLO2_TIMEOUT    -2
+#define YOLO2_INIT_ERROR -3
+#define YOLO2_MMAP_ERROR -4   /* here: allocation / mapping failure */
+#define YOLO2_DMA_ERROR  -5   /* here: host<->device copy failure */
+
+/* ------------------------------------------------------------------ tier 1: driver */
+
+/* yolo2_accel_init / yolo2_accel_cleanup (yolo2_accel_linux.h:19-31).  Binds the calling
+ * process to the HIP device selected by yolo2_hip_select_device() (default 0). */
+int  yolo2_accel_init(void);
+void yolo2_accel_cleanup(void);
+int  yolo2_hip_select_device(int device);
+int  yolo2_hip_device_count(void);
+const char *yolo2_hip_last_error(void);
+
+/* yolo2_set_q_values (yolo2_accel_linux.h:33-41): the reference latches Q values in AXI
+ * GPIOs; the per-layer calls below also take them as arguments, which win. */
+void yolo2_set_q_values(int32_t qw, int32_t qa_in, int32_t qa_out, int32_t qb);
+int  yolo2_is_busy(void);                            /* yolo2_accel_linux.h:43-47 */
+int  yolo2_is_done(void);                            /* :49-53 */
+int  yolo2_wait_for_completion(uint32_t timeout_ms); /* :55-61 */
+
+/* yolo2_execute_conv_layer (yolo2_accel_linux.h:70-99).  Same 27 arguments and meaning as
+ * YOLO2_FPGA with LayerType 0.  input/output are [C][H][W8] int16, weight is the layer's
+ * slice of weights_reorg_int16 (blocks of TM x TN x K*K), beta the layer's int16 biases.
+ * tm/tn/tr/tc/ofm_num_bound/mloops* are validated like yolo2_accel_linux.c:383-414 and
+ * otherwise unused (GPU tiling is internal and does not change results).  Blocking. */
+int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
+                             uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
+                             int input_w, int input_h, int output_w, int output_h, int padding,
+                             int is_nl, int is_bn, int tm, int tn, int tr, int tc, int ofm_num_bound,
+                             int mloopsxTM, int mloops_a1xTM, int layer_type, int qw, int qa_in,
+                             int qa_out, int qb, uint32_t timeout_ms);
+
+/* yolo2_execute_maxpool_layer (yolo2_accel_linux.h:104-121). */
+int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int channels, int ksize,
+                                int kstride, int input_w, int input_h, int output_w, int output_h,
+                                int padding, int tm, int tr, int tc, int ofm_num_bound, int mloopsxTM,
+                                int mloops_a1xTM, uint32_t timeout_ms);
+
+/* fp32 twin of the conv call (host-sim form YOLO2_FPGA without INT16_MODE,
+ * hls/models/yolov2/yolo2_accel.hpp:10-17): float tensors, Q arguments absent. */
+int yolo2_execute_conv_layer_f32(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
+                                 uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
+                                 int input_w, int input_h, int output_w, int output_h, int padding,
+                                 int is_nl, uint32_t timeout_ms);
+
+/* Buffers: dma_buffer_manager.h:94-139.  ptr is CPU-visible, phys_addr GPU-visible; both
+ * name the same mapped pinned pages, so flush/invalidate only have to order, not copy. */
+typedef struct {
+    void *ptr;
+    size_t size;
+    uint64_t phys_addr;
+} memory_buffer_t;
+int      memory_allocate_ddr(size_t size, size_t alignment, memory_buffer_t *buffer);
+void     memory_free_ddr(memory_buffer_t *buffer);
+int      memory_allocate_weights(size_t size, memory_buffer_t *buffer);
+int      memory_allocate_bias(size_t size, memory_buffer_t *buffer);
+int      memory_allocate_inference_buffer(memory_buffer_t *buffer);
+uint64_t memory_get_phys_addr(void *virt_addr);
+void     memory_flush_cache(void *addr, size_t size);
+void     memory_invalidate_cache(void *addr, size_t size);
+
+/* HBM buffers for callers that manage residency themselves. */
+int  yolo2_hip_alloc(size_t bytes, uint64_t *dev_addr);
+void yolo2_hip_free(uint64_t dev_addr);
+int  yolo2_hip_memcpy_h2d(uint64_t dst, const void *src, size_t bytes);
+int  yolo2_hip_memcpy_d2h(void *dst, uint64_t src, size_t bytes);
+int  yolo2_hip_memset(uint64_t dst, int value, size_t bytes);
+
+/* ------------------------------------------------------- tier 2: whole network, batched */
+
+typedef struct yolo2_hip_ctx yolo2_hip_ctx; /* one per device; thread-compatible */
+
+#define YOLO2_N_CONV       23
+#define YOLO2_N_WEIGHTS    50941792   /* hls/models/yolov2/yolo2_accel.cpp:41 */
+#define YOLO2_N_BIAS       10761      /* :42 */
+#define YOLO2_REGION_ELEMS (425 * 13 * 13)
+#define YOLO2_FRAME_ELEMS  (3 * 416 * 416)
+
+int  yolo2_hip_create(int device, yolo2_hip_ctx **ctx);
+void yolo2_hip_destroy(yolo2_hip_ctx *ctx);
+
+/* Weights as yolov2_hls_ps holds them after load_weights (yolo2_model.cpp:158-227): the
+ * weights_reorg_int16 stream with the per-layer file pad already stripped
+ * (yolo2_strip_int16_layer_pad below), dense int16 biases, three int32 Q tables.
+ * Uploads once, re-packs partial tiles on the device, and proves per layer which arithmetic
+ * width is exact for these weights and Q values (yolo2_hip_layer_path). */
+int yolo2_hip_load_weights_int16(yolo2_hip_ctx *ctx, const int16_t *weights_reorg, size_t n_weights,
+                                 const int16_t *bias, size_t n_bias, const int32_t *weight_q,
+                                 int n_weight_q, const int32_t *bias_q, int n_bias_q,
+                                 const int32_t *act_q, int n_act_q);
+/* Same, the two blobs already in HBM (e.g. received by an RCCL broadcast). */
+int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_dev, size_t n_weights,
+                                     uint64_t bias_dev, size_t n_bias, const int32_t *weight_q,
+                                     int n_weight_q, const int32_t *bias_q, int n_bias_q,
+                                     const int32_t *act_q, int n_act_q);
+
+/* 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 2 = 64-bit exact path,
+ * <0 = bad ordinal / not loaded.  (csrc/kernels_int16.hpp explains the forms.) */
+int yolo2_hip_layer_path(yolo2_hip_ctx *ctx, int conv_ordinal);
+
+/* (Re)allocates the activation tensors for exactly `batch` frames per call. */
+int yolo2_hip_set_batch(yolo2_hip_ctx *ctx, int batch);
+
+/* One pass of the accelerator path over a batch (everything yolov2_hls_ps does between the
+ * input memcpy and the region gather, yolo2_model.cpp:257-421, for `batch` frames):
+ *   frames_dev  float [batch][3][416][416], letterboxed, in [0,1]  (device)
+ *   region_dev  int16 [batch][425][13][13] raw region tensor       (device)
+ *   *final_q    activation Q of that tensor (float = int16 * 2^-final_q)
+ * Enqueues on `stream` (a hipStream_t, NULL = default stream) and returns without
+ * synchronising: the caller owns the one sync per batch. */
+int yolo2_hip_run_batch_int16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch,
+                              uint64_t region_dev, int *final_q, void *stream);
+
+/* Convenience for C hosts: pageable host buffers in/out, synchronous. */
+int yolo2_hip_run_batch_int16_host(yolo2_hip_ctx *ctx, const float *frames, int batch,
+                                   int16_t *region, int *final_q);
+
+/* Copies layer `layer_idx`'s output of frame `frame` from the last run into the reference's
+ * [C][H][W8] int16 layout (pad columns zero) -- the yolov2_region_*_hw.txt style parity hook
+ * (SURVEY.md section 4).  out_elems receives C*H*W8. */
+int yolo2_hip_debug_layer_output(yolo2_hip_ctx *ctx, int layer_idx, int frame, int16_t *out,
+                                 size_t capacity_elems, size_t *out_elems);
+
+/* Per-layer device time: enabling records hipEvent pairs around every layer kernel of
+ * subsequent runs, on the stream they are launched on (the analogue of the per-layer latency
+ * report in linux_app/src/yolo2_inference.c:75-142).  layer_times_ms returns the mean over the
+ * profiled runs since the last set_profiling call (at most the latest 32). */
+int yolo2_hip_set_profiling(yolo2_hip_ctx *ctx, int enable);
+int yolo2_hip_layer_times_ms(yolo2_hip_ctx *ctx, float *ms32 /* [32] */);
+
+/* Launch geometry of the conv kernel family, for the roofline report. */
+int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x, int *grid_y,
+                               int *block, int *lds_bytes, int *pixels_per_lane);
+
+/* ------------------------------------------------------------------- tier 3: helpers */
+
+/* weights_reorg_int16.bin / bias_int16.bin carry one pad element after every odd-length
+ * layer (yolo2_model.cpp:198-224).  Returns elements written, or -1 if the file is short. */
+long yolo2_strip_int16_layer_pad(const int16_t *file, size_t file_elems, const int *layer_len,
+                                 int n_layers, int16_t *dst);
+extern const int yolo2_weight_len[YOLO2_N_CONV]; /* model_config.cpp:4-7  */
+extern const int yolo2_bias_len[YOLO2_N_CONV];   /* model_config.cpp:9-10 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO2_HIP_H */

@@ -1,0 +1,263 @@
+"""GPU parity tests (run with -m gpu on the MI355X box).  Everything goes through the C ABI of
+libyolo2_hip.so; the checker is the oracle (oracle/liboracle.so) and the fixtures generated from
+the compiled reference (tests/golden).  int16: bit-exact.  fp32 per-layer: bit-exact as well
+(same operation order, no FMA contraction)."""
+import ctypes
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+from yolo2_amd import hipdrv, net, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = orclib.ROOT
+KAT = np.load(os.path.join(ROOT, "tests", "golden", "kat_layers.npz"))
+FULL = np.load(os.path.join(ROOT, "tests", "golden", "fullnet.npz"))
+
+
+def _qsets():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg.Q_SETS
+
+
+@pytest.fixture(scope="module", autouse=True)
+def driver():
+    L = hipdrv.lib()
+    assert L.yolo2_hip_device_count() >= 1, "no GPU visible: these tests must run on the GPU box"
+    hipdrv.check(L.yolo2_accel_init(), "yolo2_accel_init")
+    yield L
+    L.yolo2_accel_cleanup()
+
+
+@pytest.fixture
+def force_path(monkeypatch):
+    def _set(v):
+        if v is None:
+            monkeypatch.delenv("YOLO2_FORCE_PATH", raising=False)
+        else:
+            monkeypatch.setenv("YOLO2_FORCE_PATH", str(v))
+    return _set
+
+
+# ------------------------------------------------------------------ per-layer driver calls
+
+@pytest.mark.parametrize("path", [None, 0, 2])
+@pytest.mark.parametrize("name", [str(n) for n in KAT["conv_i16/names"]])
+def test_conv_i16_kat_bit_exact(name, path, force_path):
+    """Every known-answer conv case, through the tiled kernel's three arithmetic paths
+    (default = narrowest provably exact; 0 = 32-bit form A where legal; 2 = 64-bit)."""
+    force_path(path)
+    C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb = (int(v) for v in KAT[f"conv_i16/{name}/params"])
+    x, wr, b, y = (KAT[f"conv_i16/{name}/{k}"] for k in ("x", "w_reorg", "bias", "y"))
+    got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb, fill=0)
+    assert np.array_equal(got, y), f"{name}: {int((got != y).sum())} of {y.size} differ"
+
+
+@pytest.mark.parametrize("name", [str(n) for n in KAT["conv_f32/names"]])
+def test_conv_f32_kat_bit_exact(name):
+    C, N, K, stride, W, H, pad, leaky = (int(v) for v in KAT[f"conv_f32/{name}/params"])
+    x, wr, b, y = (KAT[f"conv_f32/{name}/{k}"] for k in ("x", "w_reorg", "bias", "y"))
+    got = hipdrv.conv_layer_f32(x, wr, b, C, N, K, stride, W, H, pad, leaky)
+    assert np.array_equal(got.view(np.uint32), y.view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", ["5x10x14", "32x26x26"])
+def test_maxpool_kat(shape):
+    C, H, W = (int(v) for v in shape.split("x"))
+    x, y = KAT[f"pool_i16/{shape}/x"], KAT[f"pool_i16/{shape}/y"]
+    assert np.array_equal(hipdrv.maxpool_layer_i16(x, C, W, H), y)
+
+
+def test_untouched_pad_columns_and_fill():
+    """Columns W..W8-1 of the output are never written (core_compute.cpp:212-220)."""
+    name = "partial_tm_tn_ragged"
+    C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb = (int(v) for v in KAT[f"conv_i16/{name}/params"])
+    x, wr, b, y = (KAT[f"conv_i16/{name}/{k}"] for k in ("x", "w_reorg", "bias", "y"))
+    got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb, fill=1234)
+    assert np.all(got[:, :, W:] == 1234)
+    assert np.array_equal(got[:, :, :W], y[:, :, :W])
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_conv_vs_oracle(seed, force_path):
+    """Random YOLO-like and ragged shapes against the oracle, all Q directions."""
+    rng = np.random.default_rng(5000 + seed)
+    K = int(rng.choice([1, 3]))
+    C, N = int(rng.integers(1, 70)), int(rng.integers(1, 100))
+    W, H = int(rng.integers(K, 60)), int(rng.integers(K, 40))
+    pad = 1 if K == 3 else 0
+    Qw, Qai, Qao, Qb = (int(rng.integers(lo, hi)) for lo, hi in ((8, 16), (6, 15), (6, 15), (4, 15)))
+    if seed % 5 == 4:
+        Qw = 1   # forces a left shift -> 64-bit path
+    amp = int(rng.choice([300, 4000, 32768]))
+    x = np.zeros((C, H, orclib.w8(W)), dtype=np.int16)
+    x[:, :, :W] = rng.integers(-amp, amp, (C, H, W)).clip(-32768, 32767)
+    w = rng.integers(-amp, amp, (N, C, K, K)).clip(-32768, 32767).astype(np.int16)
+    b = rng.integers(-32768, 32767, N).astype(np.int16)
+    wr = synth.reorg_weights(w, C, N, K)
+    leaky = int(rng.integers(0, 2))
+    want = orclib.conv_i16(x, wr, b, C, N, K, 1, W, H, pad, leaky, Qw, Qai, Qao, Qb)
+    for path in (None, 0):
+        force_path(path)
+        got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, 1, W, H, pad, leaky, Qw, Qai, Qao, Qb)
+        assert np.array_equal(got, want), (seed, path)
+
+
+def test_driver_error_codes(driver):
+    """Status codes of linux_app/include/yolo2_config.h:146-151; parameter validation like
+    yolo2_accel_linux.c:383-414."""
+    L = driver
+    buf = hipdrv.DevBuf(nbytes=4096)
+    a = buf.addr
+    ok = (a, a, a, a, 4, 4, 3, 1, 8, 8, 8, 8, 1, 1, 0, 4, 4, 8, 8, 8, 4, 8, 0, 14, 9, 9, 12, 1000)
+    bad_k = list(ok); bad_k[6] = 5
+    assert L.yolo2_execute_conv_layer(*bad_k) == hipdrv.YOLO2_ERROR
+    bad_addr = list(ok); bad_addr[0] = 0
+    assert L.yolo2_execute_conv_layer(*bad_addr) == hipdrv.YOLO2_ERROR
+    bad_type = list(ok); bad_type[22] = 1
+    assert L.yolo2_execute_conv_layer(*bad_type) == hipdrv.YOLO2_ERROR
+    bad_out = list(ok); bad_out[10] = 9
+    assert L.yolo2_execute_conv_layer(*bad_out) == hipdrv.YOLO2_ERROR
+    assert b"output size" in L.yolo2_hip_last_error()
+    buf.free()
+
+
+def test_mapped_host_buffers_like_udmabuf(driver):
+    """memory_allocate_* + memory_get_phys_addr (dma_buffer_manager.h:94-139): the CPU fills
+    ptr, the accelerator reads phys_addr, results come back through the same pages."""
+    class MB(ctypes.Structure):
+        _fields_ = [("ptr", ctypes.c_void_p), ("size", ctypes.c_size_t), ("phys_addr", ctypes.c_uint64)]
+    L = driver
+    name = "k1_linear"
+    C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb = (int(v) for v in KAT[f"conv_i16/{name}/params"])
+    x, wr, b, y = (KAT[f"conv_i16/{name}/{k}"] for k in ("x", "w_reorg", "bias", "y"))
+    bufs = []
+    for arr in (x, wr, b, np.zeros_like(y)):
+        mb = MB()
+        assert L.memory_allocate_ddr(ctypes.c_size_t(arr.nbytes), ctypes.c_size_t(4096), ctypes.byref(mb)) == 0
+        ctypes.memmove(mb.ptr, np.ascontiguousarray(arr).ctypes.data, arr.nbytes)
+        L.memory_flush_cache(ctypes.c_void_p(mb.ptr), ctypes.c_size_t(arr.nbytes))
+        bufs.append(mb)
+    addr = [L.memory_get_phys_addr(ctypes.c_void_p(m.ptr)) for m in bufs]
+    assert all(addr) and L.memory_get_phys_addr(ctypes.c_void_p(bufs[0].ptr + 64)) == addr[0] + 64
+    rc = L.yolo2_execute_conv_layer(addr[0], addr[3], addr[1], addr[2], C, N, K, stride, W, H, W, H, pad, leaky, 0,
+                                    32, 4, 13, 13, 64, 32, 64, 0, Qw, Qai, Qao, Qb, 60000)
+    assert rc == hipdrv.YOLO2_SUCCESS, L.yolo2_hip_last_error()
+    L.memory_invalidate_cache(ctypes.c_void_p(bufs[3].ptr), ctypes.c_size_t(y.nbytes))
+    got = np.ctypeslib.as_array(ctypes.cast(bufs[3].ptr, ctypes.POINTER(ctypes.c_int16)), shape=(y.size,)).reshape(y.shape)
+    assert np.array_equal(got, y)
+    for m in bufs:
+        L.memory_free_ddr(ctypes.byref(m))
+
+
+# ------------------------------------------------------------------ whole network
+
+def _diagnose(ctx, model, frame, frame_idx):
+    """Layer-by-layer diff against the oracle to localise a mismatch."""
+    _, _, _, layers = orclib.forward_i16(model, frame, dump=True)
+    for i in sorted(layers):
+        got = ctx.debug_layer_output(i, frame_idx)
+        l = net.LAYERS[i]
+        if not np.array_equal(got[:, :, :l.out_w], layers[i][:, :, :l.out_w]):
+            bad = np.argwhere(got[:, :, :l.out_w] != layers[i][:, :, :l.out_w])
+            return f"first differing layer {i} ({l.type}): {len(bad)} elems, first at {bad[0]}"
+    return "all layer tensors equal"
+
+
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_int16_bit_exact_vs_reference_fixture(qset):
+    """C2: YOLOv2 int16 single frame, bit-exact against the compiled reference's region tensor;
+    plus two more frames in the same batch against the oracle."""
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 1, 2)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    region, q = ctx.run_batch_host(frames)
+    want0 = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    assert q == int(FULL[f"i16/{qset}/final_q"])
+    if not np.array_equal(region[0], want0):
+        pytest.fail(_diagnose(ctx, model, frames[0], 0))
+    orclib.oracle().orc_set_threads(16)
+    for f in (1, 2):
+        ri, _, _ = orclib.forward_i16(model, frames[f])
+        assert np.array_equal(region[f].reshape(-1), ri), _diagnose(ctx, model, frames[f], f)
+    # dequantised tensor and region activations: same host math on identical integers
+    rf = region[0].reshape(-1).astype(np.float32) * np.float32(2.0 ** -q)
+    proc = np.zeros_like(rf)
+    orclib.oracle().orc_region_forward(rf, proc)
+    assert np.array_equal(proc, FULL[f"i16/{qset}/region_proc_f32"])
+    ctx.close()
+
+
+def test_fullnet_paths_and_64bit_fallback(monkeypatch):
+    """The same frame through the 64-bit path everywhere must give the same bits."""
+    model = synth.SynthModel(seed=1)
+    frame = synth.frames(7, 1)
+    want = FULL["i16/std/region_raw_i16"].reshape(425, 13, 13)
+    for force in ("2", "0"):
+        monkeypatch.setenv("YOLO2_FORCE_PATH", force)
+        ctx = hipdrv.Yolo2Hip(0)
+        ctx.load_model(model)
+        assert set(ctx.layer_paths()) == {int(force)}
+        region, _ = ctx.run_batch_host(frame)
+        assert np.array_equal(region[0], want), force
+        ctx.close()
+
+
+def test_extreme_weights_select_wide_path():
+    """A weight set that can overflow int32 must be routed to the 64-bit kernel by the loader."""
+    model = synth.SynthModel(seed=1)
+    model.w_reorg[5] = np.full_like(model.w_reorg[5], -32768)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    paths = ctx.layer_paths()
+    assert paths[5] == 2 and paths[6] != 2
+    frame = synth.frames(3, 1)
+    region, _ = ctx.run_batch_host(frame)
+    orclib.oracle().orc_set_threads(16)
+    ri, _, _ = orclib.forward_i16(model, frame[0])
+    assert np.array_equal(region[0].reshape(-1), ri)
+    ctx.close()
+
+
+def test_batch64_properties():
+    """C3 size (batch 64): (a) frame k of a batch equals the same frame run alone (frames are
+    independent: no cross-frame state), (b) two runs are identical, (c) a permuted batch gives
+    the permuted result, (d) frame 0 still matches the reference fixture."""
+    model = synth.SynthModel(seed=1)
+    B = 64
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(100, B - 1)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    r1, q = ctx.run_batch_host(frames)
+    r2, _ = ctx.run_batch_host(frames)
+    assert np.array_equal(r1, r2)
+    assert np.array_equal(r1[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    perm = np.random.default_rng(0).permutation(B)
+    r3, _ = ctx.run_batch_host(frames[perm])
+    assert np.array_equal(r3, r1[perm])
+    for k in (1, 17, 63):
+        single, _ = ctx.run_batch_host(frames[k:k + 1])
+        assert np.array_equal(single[0], r1[k]), k
+    assert len({r1[k].tobytes() for k in range(B)}) == B   # distinct inputs -> distinct outputs
+    ctx.close()
+
+
+def test_context_errors():
+    ctx = hipdrv.Yolo2Hip(0)
+    with pytest.raises(hipdrv.Yolo2HipError, match="load weights"):
+        ctx.set_batch(4)
+    m = synth.SynthModel(seed=1)
+    with pytest.raises(hipdrv.Yolo2HipError, match="too small"):
+        ctx.load_weights(m.weights_i16()[:1000], m.bias_i16(), m.weight_q, m.bias_q, m.act_q)
+    with pytest.raises(hipdrv.Yolo2HipError, match="Q tables too small"):
+        ctx.load_weights(m.weights_i16(), m.bias_i16(), m.weight_q[:5], m.bias_q, m.act_q)
+    with pytest.raises(hipdrv.Yolo2HipError, match="iofm_Q"):
+        ctx.load_weights(m.weights_i16(), m.bias_i16(), m.weight_q, m.bias_q, m.act_q[:0])
+    ctx.close()

@@ -1,0 +1,130 @@
+"""CPU tests of host-side logic: C-ABI surface, integer identities the kernels rely on,
+layer table, frame sharding with a real world_size-2 gloo group."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from yolo2_amd import hipdrv, net, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    hipdrv.build()
+    L = ctypes.CDLL(hipdrv.LIB_PATH)     # loads without a GPU; no compute call is made here
+    hdr = open(os.path.join(ROOT, "include", "yolo2_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:yolo2|memory)_[a-z0-9_]+)\s*\(", hdr))
+    declared |= {"yolo2_weight_len", "yolo2_bias_len"}
+    assert declared == set(hipdrv.EXPORTS), declared ^ set(hipdrv.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    L = hipdrv.lib()
+    if L.yolo2_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    assert L.yolo2_accel_init() == hipdrv.YOLO2_INIT_ERROR
+    h = ctypes.c_void_p(0)
+    assert L.yolo2_hip_create(0, ctypes.byref(h)) == hipdrv.YOLO2_INIT_ERROR
+    assert b"no CPU fallback" in L.yolo2_hip_last_error()
+    with pytest.raises(hipdrv.Yolo2HipError):
+        hipdrv.Yolo2Hip(0)
+
+
+def test_leaky_magic_division_is_exact():
+    """kernels_int16.hpp leaky_i16: floor(u/10) == (u*52429)>>19 for u in [0, 32768]."""
+    u = np.arange(0, 32769, dtype=np.uint64)
+    assert np.array_equal((u * 52429) >> 19, u // 10)
+
+
+def test_preshifted_accumulator_identity():
+    """Form B of the conv step (kernels_int16.hpp): with Bv = acc*2^s + r,
+    clamp(((Bv + p) & ~(2^s-1)) | r) == sat16(acc + ((p + r) >> s))*2^s + r."""
+    rng = np.random.default_rng(0)
+    for s in (1, 5, 14, 15):
+        r = 1 << (s - 1)
+        acc = rng.integers(-32768, 32768, 200000).astype(np.int64)
+        p = rng.integers(-(1 << 30), 1 << 30, 200000).astype(np.int64)
+        want = np.clip(acc + ((p + r) >> s), -32768, 32767) * (1 << s) + r
+        bv = acc * (1 << s) + r
+        got = np.clip(((bv + p) & ~((1 << s) - 1)) | r, (-32768 << s) + r, (32767 << s) + r)
+        assert np.array_equal(want, got)
+
+
+def test_strip_layer_pad_matches_reference_loader():
+    m = synth.SynthModel(seed=2)
+    filed = synth.SynthModel._with_layer_pad(m.bias)
+    dst = np.zeros(net.N_BIAS, dtype=np.int16)
+    lens = (ctypes.c_int * 23)(*net.BIAS_LEN)
+    n = hipdrv.lib().yolo2_strip_int16_layer_pad(filed.ctypes.data_as(ctypes.c_void_p), filed.size, lens, 23,
+                                                 dst.ctypes.data_as(ctypes.c_void_p))
+    assert n == net.N_BIAS and np.array_equal(dst, m.bias_i16())
+    assert hipdrv.lib().yolo2_strip_int16_layer_pad(filed.ctypes.data_as(ctypes.c_void_p), 100, lens, 23,
+                                                    dst.ctypes.data_as(ctypes.c_void_p)) == -1
+    wl = (ctypes.c_int * 23).in_dll(hipdrv.lib(), "yolo2_weight_len")
+    bl = (ctypes.c_int * 23).in_dll(hipdrv.lib(), "yolo2_bias_len")
+    assert list(wl) == net.WEIGHT_LEN and list(bl) == net.BIAS_LEN
+
+
+def test_layer_table_totals():
+    assert net.N_WEIGHTS == 50941792 and net.N_BIAS == 10761
+    assert net.macs_per_frame() == 14732084224
+    assert net.requant_steps_per_frame() == 3695481088
+    assert net.activation_elems_per_frame() == 38663313
+    assert len(net.LAYERS) == 32 and len(net.CONVS) == 23
+
+
+def test_shard_range_covers_everything():
+    from yolo2_amd import dist as ydist
+    for total, world in [(2048, 8), (10, 4), (3, 8), (64, 1)]:
+        got = [ydist.shard_range(total, r, world) for r in range(world)]
+        assert got[0][0] == 0 and got[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        assert max(h - l for l, h in got) - min(h - l for l, h in got) <= 1
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "yolo-fpga-accelerator_amd"))
+    from yolo2_amd import dist as ydist, synth as s
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = s.SynthModel(seed=4) if rank == 0 else None
+    w, b, wq, bq, aq = ydist.broadcast_model(model, torch.device("cpu"))
+    lo, hi = ydist.shard_range(10, rank, world)
+    frames = s.frames(11, hi - lo, first=lo)
+    # every rank reports a checksum of what it received and of its frame shard
+    q.put((rank, int(w.to(torch.int64).sum()), int(b.to(torch.int64).sum()), list(map(int, aq)),
+           lo, hi, float(frames.astype(np.float64).sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_weight_broadcast_and_frame_sharding_world2_gloo():
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    ref = synth.SynthModel(seed=4)
+    for rank, ws, bs, aq, lo, hi, fs in res:
+        assert ws == int(ref.weights_i16().astype(np.int64).sum())
+        assert bs == int(ref.bias_i16().astype(np.int64).sum())
+        assert aq == list(map(int, ref.act_q))
+    assert (res[0][4], res[0][5], res[1][4], res[1][5]) == (0, 5, 5, 10)
+    whole = synth.frames(11, 10).astype(np.float64)
+    assert abs(res[0][6] - whole[:5].sum()) < 1e-6 and abs(res[1][6] - whole[5:].sum()) < 1e-6

@@ -1,0 +1,504 @@
+// kernels_int16.hpp -- hand-written gfx950 kernels for the int16 fixed-point YOLOv2 path.
+//
+// What is computed (bit-exact target, SURVEY.md 8a "equivalent per-output definition",
+// restating hls/core/core_compute.cpp:22-120 + :175-210):
+//   acc = shift(bias[m], Qb-Qa_out)                               (not saturated)
+//   for each 4-input-channel group, for each tap (i,j):
+//       p   = sum_{t<4} w[m][4g+t][i][j] * in[4g+t][y+i-pad][x+j-pad]
+//       acc = sat16(acc + shift_round(p, Qa_in+Qw-Qa_out))
+//   out = leaky ? (acc<0 ? acc/10 : acc) : acc
+// The per-(group,tap) round+saturate makes this an integer-VALU problem, not a GEMM: there is
+// no int16 MFMA on CDNA4 and a wider contraction would change results.  The kernel is built
+// around the 5-instruction step  v_dot2 / v_dot2 / v_ashrrev / v_add / v_med3  per
+// (4 channels x 1 tap x 1 output) with every operand already in registers:
+//   * weights are wave-uniform -> scalar loads (s_load_dwordx16 per tap), SGPR operands;
+//   * the input tile of one channel group is staged once per workgroup in LDS and shared by
+//     the 4 wavefronts, each of which owns 8 of the workgroup's 32 output channels;
+//   * lanes own consecutive pixels (conflict-free ds_read_b64, coalesced 8-byte stores),
+//     P pixels per lane x 8 channels = 8P int32 accumulators in VGPRs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <type_traits>
+
+#include "layout.hpp"
+
+namespace y2 {
+
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+struct ConvArgs {
+    int B, H, W, Wp, PL;       // geometry shared by input and output ('same' conv, stride 1)
+    int CGin;                  // input channel groups
+    int CGout;                 // output channel groups that exist in the destination tensor
+    int npix;                  // B*H*W
+    long in_cg_stride;         // items
+    long out_cg_stride;        // items
+    long out_base;             // item offset of output group 0 (concat placement), incl. lead
+    int shift, round;          // fast path: 0 <= shift <= 30, round = shift ? 1<<(shift-1) : 0
+    int sh_right, sh_left;     // exact path: direction flags, magnitude = shift
+    int bs_right, bs_left, bs_mag;  // bias shift (exact path computes it itself)
+    int leaky;
+    int lt_max;                // LDS tile capacity in items
+};
+
+// core_compute.cpp:191-197: x<0 ? x/10 (C division, toward zero) : x.  For u in [1,32768]
+// floor(u/10) == (u*52429)>>19 (checked exhaustively in tests/test_host_logic.py).
+__device__ __forceinline__ int leaky_i16(int v)
+{
+    const unsigned u = (unsigned)(-v);
+    const int q = (int)((u * 52429u) >> 19);
+    return v < 0 ? -q : v;
+}
+
+__device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767); }
+
+// ---- the requantise-and-saturate step, 32-bit forms ------------------------------------------
+//
+// Form A (always valid under the int32 bound): for the 8 output channels of a wavefront and one
+// (pixel, tap):  t[m] = (dot4(w[m], x) + round) >> shift, then acc = med3(acc + t) in C++.
+// 3 instructions per step here + 2 outside = 5 per step.  Written as ONE asm statement because
+//  * hipcc's sdot2 builtin selects the VOP2 v_dot2c form and adds a v_mov per step to seed the
+//    accumulator; the VOP3P v_dot2_i32_i16 takes the rounding constant as src2 for free;
+//  * gfx950 needs wait states between a DOT result and a different VALU reading it, which hipcc
+//    does not pad inside/after asm (cdna_hip_programming.md 5.7 item 2).  The order below keeps
+//    every dependent pair 8 instructions apart, so no s_nop is needed at all.
+// Operands: w = SGPRs (one constant-bus read per instruction), x/r = VGPRs, shift = SGPR.
+__device__ __forceinline__ void dot8_shift(int (&t)[8], const int2 x, const int2 (&w)[8], const int r, const int s)
+{
+    asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
+        "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
+        "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
+        "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
+        "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
+        "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
+        "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
+        "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
+        "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %25, %7\n\t"
+        "v_ashrrev_i32 %0, %27, %0\n\t"
+        "v_ashrrev_i32 %1, %27, %1\n\t"
+        "v_ashrrev_i32 %2, %27, %2\n\t"
+        "v_ashrrev_i32 %3, %27, %3\n\t"
+        "v_ashrrev_i32 %4, %27, %4\n\t"
+        "v_ashrrev_i32 %5, %27, %5\n\t"
+        "v_ashrrev_i32 %6, %27, %6\n\t"
+        "v_ashrrev_i32 %7, %27, %7"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
+        : "s"(w[0].x), "s"(w[1].x), "s"(w[2].x), "s"(w[3].x), "s"(w[4].x), "s"(w[5].x), "s"(w[6].x), "s"(w[7].x),
+          "s"(w[0].y), "s"(w[1].y), "s"(w[2].y), "s"(w[3].y), "s"(w[4].y), "s"(w[5].y), "s"(w[6].y), "s"(w[7].y),
+          "v"(x.x), "v"(x.y), "v"(r), "s"(s));
+}
+
+// Form B (4 instructions per step, needs the tighter bound checked by the host): keep the
+// accumulator pre-shifted, Bv = acc*2^s + round.  Then
+//     Bv' = clamp( ((Bv + p) & ~(2^s-1)) | round )        with bounds  {-32768,32767}*2^s + round
+// equals (sat16(acc + ((p + round) >> s)))*2^s + round exactly (floor division distributes over the
+// multiple-of-2^s part), and p is accumulated straight into Bv by two v_dot2c: no seed, no shift.
+__device__ __forceinline__ int stepB(int Bv, const int2 x, const int2 w, const int nmask, const int r, const int lo, const int hi)
+{
+    Bv = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w.x), Bv, false);
+    Bv = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w.y), Bv, false);
+    Bv = (Bv & nmask) | r;
+    // min(max()) only folds to v_med3_i32 when hipcc can prove lo <= hi; say it directly.
+    // (plain VALU -> VALU: no wait states involved; lo in an SGPR, hi in a VGPR)
+    int o;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(o) : "v"(Bv), "s"(lo), "v"(hi));
+    return o;
+}
+
+__device__ __forceinline__ long shift64(long v, int right, int left, int mag, long round)
+{
+    if (right) return (v + round) >> mag;
+    if (left) return (long)((unsigned long)v << mag);
+    return v;
+}
+
+__device__ __forceinline__ long step64(long acc, int2 x, int2 w, const ConvArgs &a)
+{
+    const int x0 = (short)(x.x & 0xffff), x1 = x.x >> 16, x2 = (short)(x.y & 0xffff), x3 = x.y >> 16;
+    const int w0 = (short)(w.x & 0xffff), w1 = w.x >> 16, w2 = (short)(w.y & 0xffff), w3 = w.y >> 16;
+    // each int16 x int16 product fits int32; widen once per product like core_compute.cpp:102-106
+    const long p = (long)(w0 * x0) + (long)(w1 * x1) + (long)(w2 * x2) + (long)(w3 * x3);
+    long v = acc + shift64(p, a.sh_right, a.sh_left, a.shift, a.sh_right && a.shift > 0 ? (1L << (a.shift - 1)) : 0);
+    v = v > 32767 ? 32767 : v;
+    v = v < -32768 ? -32768 : v;
+    return v;
+}
+
+// Pixel index q (raster over b, y, x of real pixels) -> flat item offset inside a channel group.
+__device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
+{
+    const int b = q / HW;
+    const int r = q - b * HW;
+    const int y = r / W;
+    const int x = r - y * W;
+    return b * PL + (y + 1) * Wp + x;
+}
+
+// Conv KSxKS, stride 1, 'same' padding, on the item layout.
+//   grid.x = ceil(npix / (64*P)) pixel tiles, grid.y = output-channel blocks of 32
+//   block  = 256 threads = 4 wavefronts; wavefront w owns channels [32*by + 8w, +8)
+// MODE 0: 32-bit form A, valid when the host proved no intermediate leaves int32.
+// MODE 1: 32-bit form B (pre-shifted accumulator), tighter bound, 4 instructions per step.
+// MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
+template <int KS, int P, int MODE>
+__global__ __launch_bounds__(256) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
+                                                   const int2 *__restrict__ wpk,
+                                                   const short *__restrict__ bias, const ConvArgs a)
+{
+    extern __shared__ int2 lds[];
+    constexpr bool X64 = MODE == 2;
+    typedef typename std::conditional<X64, long, int>::type acc_t;
+    constexpr int T = 64 * P;
+    constexpr int KK = KS * KS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mb = blockIdx.y;
+    const int HW = a.H * a.W;
+    const int q0 = blockIdx.x * T;
+    const int qlast = min(q0 + T, a.npix) - 1;
+    const int halo = (KS == 3) ? a.Wp + 1 : 0;
+    const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL);
+    const int fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
+    const int tile_start = fmin - halo;
+    const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
+
+    int fo[P];        // flat item offset of each owned pixel (also its output address)
+    int rowaddr[P][KS];  // LDS byte address of (row i-1, col -1) relative tap origin per pixel
+    bool valid[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int q = q0 + p * 64 + lane;
+        valid[p] = q <= qlast;
+        fo[p] = flat_of(min(q, qlast), HW, a.W, a.Wp, a.PL);
+        const int lo = fo[p] - tile_start;
+#pragma unroll
+        for (int i = 0; i < KS; ++i)
+            rowaddr[p][i] = (KS == 3) ? (lo + (i - 1) * a.Wp - 1) * 8 : lo * 8;
+    }
+
+    // bias moved to the Qa_out domain, not saturated (core_compute.cpp:86-97)
+    acc_t acc[P][8];
+    {
+        const short *bp = bias + mb * 32 + wave * 8;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            acc_t b0;
+            if (X64) {
+                b0 = (acc_t)shift64((long)bp[m], a.bs_right, a.bs_left, a.bs_mag,
+                                    a.bs_right && a.bs_mag > 0 ? (1L << (a.bs_mag - 1)) : 0);
+            } else {
+                const int b = bp[m];
+                b0 = a.bs_right ? (acc_t)((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag)
+                                : (a.bs_left ? (acc_t)(b << a.bs_mag) : (acc_t)b);
+                if (MODE == 1) b0 = (acc_t)(((int)b0 << a.shift) + a.round);
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p][m] = b0;
+        }
+    }
+
+    const int r = a.round, s = a.shift;
+    const int nmask = ~((1 << s) - 1), lo_b = (int)(0xffff8000u << s) + r, hi_b = (32767 << s) + r;
+    // Form B wants v_and_or_b32 (mask in an SGPR, round in a VGPR: one constant-bus operand);
+    // hide the uniformity of `round` so hipcc keeps it in a VGPR instead of splitting and/or.
+    int r_vgpr = r;
+    if (MODE == 1) asm volatile("" : "+v"(r_vgpr));
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    const int2 *src = in + kLead + tile_start;
+    const int2 *wq = wpk + ((long)mb * a.CGin * KK * 32 + wave * 8);
+
+    for (int cg = 0; cg < a.CGin; ++cg) {
+        __syncthreads();  // everyone is done reading the previous tile
+        for (int i = tid; i < Lt; i += 256) lds[i] = src[i];
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            int2 w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const int2 x = *reinterpret_cast<const int2 *>(lds_b + rowaddr[p][tap / KS] + (tap % KS) * 8);
+                if (MODE == 0) {
+                    int t[8];
+                    dot8_shift(t, x, w, r, s);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[p][m] = (acc_t)clamp16((int)acc[p][m] + t[m]);
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        if (MODE == 2) acc[p][m] = (acc_t)step64((long)acc[p][m], x, w[m], a);
+                        else acc[p][m] = (acc_t)stepB((int)acc[p][m], x, w[m], nmask, r_vgpr, lo_b, hi_b);
+                    }
+                }
+            }
+        }
+        src += a.in_cg_stride;
+        wq += KK * 32;
+    }
+
+    // write-back with integer leaky (core_compute.cpp:175-264): 2 items (8 channels) per pixel
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int cgo = mb * 8 + wave * 2 + g;
+        if (cgo >= a.CGout) continue;
+        int2 *dst = out + a.out_base + (long)cgo * a.out_cg_stride;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            int v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int e = (int)acc[p][g * 4 + t];
+                if (MODE == 1) e >>= s;  // back from the pre-shifted domain
+                v[t] = a.leaky ? leaky_i16(e) : e;
+            }
+            int2 o;
+            o.x = (v[0] & 0xffff) | (v[1] << 16);
+            o.y = (v[2] & 0xffff) | (v[3] << 16);
+            if (valid[p]) dst[fo[p]] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ small kernels
+
+// float [B][3][416][416] -> quantised items (C=3, 4th lane 0).  yolo2_model.cpp:257-273.
+__global__ void k_pack_input(const float *__restrict__ frames, int2 *__restrict__ out, int B, int H, int W,
+                             int Wp, int PL, float scale)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int HW = H * W;
+    if (q >= B * HW) return;
+    const int b = q / HW, r = q - b * HW;
+    int v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float f = frames[((long)b * 3 + c) * HW + r] * scale;
+        f = fminf(fmaxf(f, -32768.f), 32767.f);
+        v[c] = clamp16((int)roundf(f));  // llround: half away from zero
+    }
+    const int y = r / W, x = r - y * W;
+    int2 o;
+    o.x = (v[0] & 0xffff) | (v[1] << 16);
+    o.y = (v[2] & 0xffff);
+    out[kLead + (long)b * PL + (long)(y + 1) * Wp + x] = o;
+}
+
+__device__ __forceinline__ int pkmax(int a, int b)
+{
+    short2_t r = __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b));
+    return __builtin_bit_cast(int, r);
+}
+
+// 2x2 stride-2 max pool on items (pool_yolo2, core_compute.cpp:266-305; even H, W: no edge).
+__global__ void k_maxpool2(const int2 *__restrict__ in, int2 *__restrict__ out, int CG, int B, int OH, int OW,
+                           int iWp, int iPL, int oWp, int oPL)
+{
+    const long n = (long)CG * B * OH * OW;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int x = (int)(t % OW);
+    const int y = (int)((t / OW) % OH);
+    const long pb = t / ((long)OW * OH);  // cg*B + b
+    const int2 *s = in + kLead + pb * iPL + (long)(2 * y + 1) * iWp + 2 * x;
+    const int2 a = s[0], b = s[1], c = s[iWp], d = s[iWp + 1];
+    int2 o;
+    o.x = pkmax(pkmax(a.x, b.x), pkmax(c.x, d.x));
+    o.y = pkmax(pkmax(a.y, b.y), pkmax(c.y, d.y));
+    out[kLead + pb * oPL + (long)(y + 1) * oWp + x] = o;
+}
+
+// Darknet legacy reorg (stride 2) of the 64x26x26 tensor + route-28 Q alignment shift
+// (yolo2_model.cpp:112-129, 358-403): out[i + 26*(j + 416*k)] = x[(2i + k%2) + 52*(2j + k/2)]
+// over flat [64*26*26]; destination is channel groups [0,64) of the 1280-channel concat tensor.
+__global__ void k_reorg(const short *__restrict__ in, short *__restrict__ out, int B, int iWp, int iPL,
+                        long i_cg_stride, int oWp, int oPL, long o_cg_stride, int shift)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over B * 256*169 output elements
+    if (t >= B * 256 * 169) return;
+    const int b = t / (256 * 169);
+    const int o = t - b * (256 * 169);  // flat [256][13][13] == flat i + 26*(j + 416*k)
+    const int k = o / (26 * 416);
+    const int rem = o - k * (26 * 416);
+    const int j = rem / 26, i = rem - j * 26;
+    const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));  // flat [64][26][26]
+    const int sc = sidx / 676, sr = sidx - sc * 676;
+    const int sy = sr / 26, sx = sr - sy * 26;
+    int v = in[(kLead + (long)(sc >> 2) * i_cg_stride + (long)b * iPL + (long)(sy + 1) * iWp + sx) * 4 + (sc & 3)];
+    if (shift > 0) v >>= shift;                 // arithmetic, no rounding (yolo2_model.cpp:387-388)
+    else if (shift < 0) v = (int)((unsigned)v << (-shift));
+    v = clamp16(v);
+    const int oc = o / 169, orr = o - oc * 169;
+    const int oy = orr / 13, ox = orr - oy * 13;
+    out[(kLead + (long)(oc >> 2) * o_cg_stride + (long)b * oPL + (long)(oy + 1) * oWp + ox) * 4 + (oc & 3)] = (short)v;
+}
+
+// items (C channels) -> dense [B][C][H][W] int16 (the 13-of-16 region gather, yolo2_model.cpp:406-414)
+__global__ void k_unpack_dense(const short *__restrict__ in, short *__restrict__ out, int B, int C, int H, int W,
+                               int Wp, int PL, long cg_stride)
+{
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)B * C * H * W;
+    if (t >= n) return;
+    const int x = (int)(t % W);
+    const int y = (int)((t / W) % H);
+    const int c = (int)((t / ((long)W * H)) % C);
+    const int b = (int)(t / ((long)W * H * C));
+    out[t] = in[(kLead + (long)(c >> 2) * cg_stride + (long)b * PL + (long)(y + 1) * Wp + x) * 4 + (c & 3)];
+}
+
+// reference layout [C][H][W8] -> items (B = 1), and back (pad columns of the destination untouched,
+// like the reference's row write-back of TC_MIN elements, core_compute.cpp:212-220)
+__global__ void k_ref_to_items(const short *__restrict__ in, short *__restrict__ out, int C, int H, int W, int W8,
+                               int Wp, long cg_stride)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * H * W) return;
+    const int x = t % W, y = (t / W) % H, c = t / (W * H);
+    out[(kLead + (long)(c >> 2) * cg_stride + (long)(y + 1) * Wp + x) * 4 + (c & 3)] = in[((long)c * H + y) * W8 + x];
+}
+
+__global__ void k_items_to_ref(const short *__restrict__ in, short *__restrict__ out, int C, int H, int W, int W8,
+                               int Wp, int PL, long cg_stride, int b)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * H * W) return;
+    const int x = t % W, y = (t / W) % H, c = t / (W * H);
+    out[((long)c * H + y) * W8 + x] = in[(kLead + (long)(c >> 2) * cg_stride + (long)b * PL + (long)(y + 1) * Wp + x) * 4 + (c & 3)];
+}
+
+// weights_reorg stream of one layer -> wpk[MB][CG][KK][32][4] with partial tiles zero-padded.
+// Source block (m0,n0) starts at m0*C*KK + TM_MIN*n0*KK and is [kk][TM_MIN][TN_MIN]
+// (yolov2_weight_gen.cpp:43-67; consumed in this order by core_io.cpp:154-198).
+template <typename T>
+__global__ void k_repack_weights(const T *__restrict__ src, T *__restrict__ dst, int C, int N, int KK)
+{
+    const int CG = (C + kTn - 1) / kTn, MB = (N + kTm - 1) / kTm;
+    const long n = (long)MB * CG * KK * 128;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int tn = (int)(t & 3), tm = (int)((t >> 2) & 31);
+    const long r = t >> 7;
+    const int tap = (int)(r % KK);
+    const int cg = (int)((r / KK) % CG);
+    const int mb = (int)(r / ((long)KK * CG));
+    const int m0 = mb * kTm, n0 = cg * kTn;
+    const int tm_min = min(kTm, N - m0), tn_min = min(kTn, C - n0);
+    T v = 0;
+    if (tm < tm_min && tn < tn_min)
+        v = src[(long)m0 * C * KK + (long)tm_min * n0 * KK + (long)tap * tm_min * tn_min + tm * tn_min + tn];
+    dst[t] = v;
+}
+
+// max over (m, group, tap) of sum_t |w_t| on the packed weights: the 32-bit exactness bound.
+__global__ void k_weight_bound(const short *__restrict__ wpk, long n_quads, int *__restrict__ result)
+{
+    long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int best = 0;
+    for (; t < n_quads; t += (long)gridDim.x * blockDim.x) {
+        const short *w = wpk + t * 4;
+        int s = abs((int)w[0]) + abs((int)w[1]) + abs((int)w[2]) + abs((int)w[3]);
+        best = max(best, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(result, best);
+}
+
+// ------------------------------------------------------------------ generic reference-layout kernels
+// One thread per output element, reference arithmetic verbatim (64-bit), any K<=3, stride<=2,
+// padding<=4.  Used by the per-layer driver calls for shapes the tiled kernel does not cover,
+// and as an independent second implementation in the GPU tests.
+__global__ void k_conv_ref_i16(const short *__restrict__ in, short *__restrict__ out, const short *__restrict__ w,
+                               const short *__restrict__ bias, int C, int N, int K, int stride, int W, int H,
+                               int OW, int OH, int pad, int leaky, int so, int sb)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * OH * OW) return;
+    const int x = t % OW, y = (t / OW) % OH, m = t / (OW * OH);
+    const int W8 = (W + 7) & ~7, OW8 = (OW + 7) & ~7, KK = K * K;
+    const int so_r = so > 0, so_l = so < 0, so_m = min(so_r ? so : -so, 30);
+    const int sb_r = sb > 0, sb_l = sb < 0, sb_m = min(sb_r ? sb : -sb, 30);
+    long acc = shift64((long)bias[m], sb_r, sb_l, sb_m, sb_r && sb_m > 0 ? (1L << (sb_m - 1)) : 0);
+    const int m0 = m / kTm * kTm, tm = m - m0, tm_min = min(kTm, N - m0);
+    for (int n0 = 0; n0 < C; n0 += kTn) {
+        const int tn_min = min(kTn, C - n0);
+        const short *wb = w + (long)m0 * C * KK + (long)tm_min * n0 * KK;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const int sy = y * stride + i - pad, sx = x * stride + j - pad;
+                const bool inb = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                long p = 0;
+                for (int tt = 0; tt < tn_min; ++tt) {
+                    const int wv = wb[(long)(i * K + j) * tm_min * tn_min + tm * tn_min + tt];
+                    const int xv = inb ? in[((long)(n0 + tt) * H + sy) * W8 + sx] : 0;
+                    p += (long)(wv * xv);
+                }
+                long v = acc + shift64(p, so_r, so_l, so_m, so_r && so_m > 0 ? (1L << (so_m - 1)) : 0);
+                acc = v > 32767 ? 32767 : (v < -32768 ? -32768 : v);
+            }
+    }
+    int e = (int)acc;
+    if (leaky) e = leaky_i16(e);
+    out[((long)m * OH + y) * OW8 + x] = (short)clamp16(e);
+}
+
+// fp32 twin, reference operation order with no FMA contraction (core_compute.cpp:121-172, :201-205)
+__global__ void k_conv_ref_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ w,
+                               const float *__restrict__ bias, int C, int N, int K, int stride, int W, int H,
+                               int OW, int OH, int pad, int leaky)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * OH * OW) return;
+    const int x = t % OW, y = (t / OW) % OH, m = t / (OW * OH);
+    const int W8 = (W + 7) & ~7, OW8 = (OW + 7) & ~7, KK = K * K;
+    const int m0 = m / kTm * kTm, tm = m - m0, tm_min = min(kTm, N - m0);
+    float acc = bias[m];
+    for (int n0 = 0; n0 < C; n0 += kTn) {
+        const int tn_min = min(kTn, C - n0);
+        const float *wb = w + (long)m0 * C * KK + (long)tm_min * n0 * KK;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const int sy = y * stride + i - pad, sx = x * stride + j - pad;
+                const bool inb = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                float ps = 0.f;
+                for (int tt = 0; tt < kTn; ++tt) {
+                    const float wv = tt < tn_min ? wb[(long)(i * K + j) * tm_min * tn_min + tm * tn_min + tt] : 0.f;
+                    const float xv = (inb && tt < tn_min) ? in[((long)(n0 + tt) * H + sy) * W8 + sx] : 0.f;
+                    ps = __fadd_rn(ps, __fmul_rn(wv, xv));
+                }
+                acc = __fadd_rn(acc, ps);
+            }
+    }
+    if (leaky && acc < 0.0f) acc = __fmul_rn(acc, 0.1f);
+    out[((long)m * OH + y) * OW8 + x] = acc;
+}
+
+// any KxK / stride pool with the reference's pad value (core_io.cpp:96-103), reference layout
+template <typename T>
+__global__ void k_pool_ref(const T *__restrict__ in, T *__restrict__ out, int C, int K, int stride, int W, int H,
+                           int OW, int OH, T padv)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= C * OH * OW) return;
+    const int x = t % OW, y = (t / OW) % OH, c = t / (OW * OH);
+    const int W8 = (W + 7) & ~7, OW8 = (OW + 7) & ~7;
+    T best = padv;
+    for (int i = 0; i < K; ++i)
+        for (int j = 0; j < K; ++j) {
+            const int sy = y * stride + i, sx = x * stride + j;
+            const T v = (sy < H && sx < W) ? in[((long)c * H + sy) * W8 + sx] : padv;
+            if (v > best) best = v;
+        }
+    out[((long)c * OH + y) * OW8 + x] = best;
+}
+
+}  // namespace y2

@@ -1,0 +1,920 @@
+// yolo2_hip.hip -- C ABI of libyolo2_hip.so (include/yolo2_hip.h) and the launch logic.
+//
+// Tier 1 mirrors the reference's userspace driver (linux_app/src/yolo2_accel_linux.c:419-575,
+// dma_buffer_manager.c) call for call; tier 2 restates the layer loop of yolov2_hls_ps
+// (hls/models/yolov2/yolo2_model.cpp:229-449) as 28+3 kernel launches per batch on one stream.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/yolo2_hip.h"
+#include "kernels_int16.hpp"
+#include "layout.hpp"
+
+using namespace y2;
+
+// ---------------------------------------------------------------------------- errors
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    if (getenv("YOLO2_VERBOSE")) fprintf(stderr, "[yolo2_hip] %s\n", g_err);
+    return code;
+}
+
+#define HIP_TRY(expr, code)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *yolo2_hip_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------- model tables
+
+extern "C" const int yolo2_weight_len[YOLO2_N_CONV] = {864, 18432, 73728, 8192, 73728, 294912, 32768, 294912,
+                                                       1179648, 131072, 1179648, 131072, 1179648, 4718592,
+                                                       524288, 4718592, 524288, 4718592, 9437184, 9437184,
+                                                       32768, 11796480, 435200};
+extern "C" const int yolo2_bias_len[YOLO2_N_CONV] = {32, 64, 128, 64, 128, 256, 128, 256, 512, 256, 512, 256,
+                                                     512, 1024, 512, 1024, 512, 1024, 1024, 1024, 64, 1024, 425};
+
+extern "C" long yolo2_strip_int16_layer_pad(const int16_t *file, size_t file_elems, const int *layer_len,
+                                            int n_layers, int16_t *dst)
+{
+    size_t fo = 0, oo = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const size_t len = (size_t)layer_len[l];
+        if (fo + len > file_elems) return -1;
+        memcpy(dst + oo, file + fo, len * sizeof(int16_t));
+        fo += len + (len & 1);  // yolo2_model.cpp:215-220
+        oo += len;
+    }
+    return (long)oo;
+}
+
+enum LType { L_CONV, L_MAX, L_ROUTE, L_REORG, L_REGION };
+struct LayerDesc {
+    LType type;
+    int c, h, w, n, size, leaky;
+};
+// config/yolov2.cfg as parsed by the reference; the C host re-derives the same
+// table from the .cfg file and checks it against this one before using the batched entry.
+static const LayerDesc kNet[32] = {
+    {L_CONV, 3, 416, 416, 32, 3, 1},    {L_MAX, 32, 416, 416, 32, 2, 0},   {L_CONV, 32, 208, 208, 64, 3, 1},
+    {L_MAX, 64, 208, 208, 64, 2, 0},    {L_CONV, 64, 104, 104, 128, 3, 1}, {L_CONV, 128, 104, 104, 64, 1, 1},
+    {L_CONV, 64, 104, 104, 128, 3, 1},  {L_MAX, 128, 104, 104, 128, 2, 0}, {L_CONV, 128, 52, 52, 256, 3, 1},
+    {L_CONV, 256, 52, 52, 128, 1, 1},   {L_CONV, 128, 52, 52, 256, 3, 1},  {L_MAX, 256, 52, 52, 256, 2, 0},
+    {L_CONV, 256, 26, 26, 512, 3, 1},   {L_CONV, 512, 26, 26, 256, 1, 1},  {L_CONV, 256, 26, 26, 512, 3, 1},
+    {L_CONV, 512, 26, 26, 256, 1, 1},   {L_CONV, 256, 26, 26, 512, 3, 1},  {L_MAX, 512, 26, 26, 512, 2, 0},
+    {L_CONV, 512, 13, 13, 1024, 3, 1},  {L_CONV, 1024, 13, 13, 512, 1, 1}, {L_CONV, 512, 13, 13, 1024, 3, 1},
+    {L_CONV, 1024, 13, 13, 512, 1, 1},  {L_CONV, 512, 13, 13, 1024, 3, 1}, {L_CONV, 1024, 13, 13, 1024, 3, 1},
+    {L_CONV, 1024, 13, 13, 1024, 3, 1}, {L_ROUTE, 0, 0, 0, 0, 0, 0},       {L_CONV, 512, 26, 26, 64, 1, 1},
+    {L_REORG, 64, 26, 26, 256, 0, 0},   {L_ROUTE, 0, 0, 0, 0, 0, 0},       {L_CONV, 1280, 13, 13, 1024, 3, 1},
+    {L_CONV, 1024, 13, 13, 425, 1, 0},  {L_REGION, 425, 13, 13, 0, 0, 0},
+};
+
+// ---------------------------------------------------------------------------- launch helpers
+
+struct ShiftSpec {
+    int right, left, mag;
+};
+static ShiftSpec make_shift(int s)  // core_compute.cpp:48-63: magnitude capped at 30
+{
+    ShiftSpec sh;
+    sh.right = s > 0;
+    sh.left = s < 0;
+    int a = sh.right ? s : (sh.left ? -s : 0);
+    sh.mag = a > 30 ? 30 : a;
+    return sh;
+}
+
+// 32-bit exactness: no intermediate of the fast kernel may leave int32.
+//   |p + round| <= maxsum*32768 + round ;  |acc + scaled| <= max(32768,|bias0|) + |p + round|
+// Form B keeps acc*2^s + round in the register:  max(32768,|bias0|)*2^s + round + |p| must fit.
+// Returns 0 (form A), 1 (form B) or 2 (64-bit).
+static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
+{
+    if (so < 0) return 2;
+    const ShiftSpec o = make_shift(so), b = make_shift(sb);
+    const long long round = o.mag > 0 ? (1LL << (o.mag - 1)) : 0;
+    long long bias0 = max_abs_bias;
+    if (b.right) bias0 = ((bias0 + (b.mag > 0 ? (1LL << (b.mag - 1)) : 0)) >> b.mag) + 1;
+    else if (b.left) bias0 = bias0 << b.mag;
+    const long long accmax = std::max<long long>(32768, bias0);
+    const long long pmax = (long long)maxsum * 32768;
+    if (bias0 > 2147483647LL) return 2;
+    int path = 2;
+    if (pmax + round + accmax <= 2147483647LL) path = 0;
+    if ((accmax << o.mag) + round + pmax <= 2147483647LL) path = 1;
+    const char *force = getenv("YOLO2_FORCE_PATH");  // test hook: 0/1 only when legal, 2 always
+    if (force) {
+        const int f = atoi(force);
+        if (f == 2 || (f == 0 && path != 2)) path = f;
+    }
+    return path;
+}
+
+struct ConvPlan {
+    int C = 0, N = 0, K = 0, H = 0, W = 0, leaky = 0;
+    int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
+    int path = 0;  // 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 2 = 64-bit
+    int P = 8;
+    dim3 grid;
+    int lds_bytes = 0;
+    ConvArgs args;
+};
+
+static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long out_base, int CGout)
+{
+    const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
+    p.P = p.path == 2 ? 4 : 8;
+    // small problems (single frame): fewer pixels per lane -> more workgroups
+    const int npix = gin.B * gin.H * gin.W;
+    while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * ((p.N + 31) / 32) < 1024) p.P >>= 1;
+    const int T = 64 * p.P;
+    const int halo = p.K == 3 ? gin.Wp + 1 : 0;
+    ConvArgs &a = p.args;
+    a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
+    a.CGin = gin.CG;
+    a.CGout = CGout;
+    a.npix = npix;
+    a.in_cg_stride = gin.cg_stride;
+    a.out_cg_stride = out_cg_stride;
+    a.out_base = out_base;
+    a.shift = so.mag;
+    a.round = (so.right && so.mag > 0) ? (1 << (so.mag - 1)) : 0;
+    a.sh_right = so.right; a.sh_left = so.left;
+    a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
+    a.leaky = p.leaky;
+    a.lt_max = tile_items_bound(gin, T, halo);
+    p.lds_bytes = a.lt_max * 8;
+    p.grid = dim3((npix + T - 1) / T, (p.N + 31) / 32, 1);
+}
+
+template <int KS, int MODE>
+static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias,
+                          hipStream_t st)
+{
+    switch (p.P) {
+    case 8: hipLaunchKernelGGL((k_conv_i16<KS, 8, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
+    case 4: hipLaunchKernelGGL((k_conv_i16<KS, 4, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
+    case 2: hipLaunchKernelGGL((k_conv_i16<KS, 2, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
+    default: hipLaunchKernelGGL((k_conv_i16<KS, 1, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
+    }
+}
+
+static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
+{
+    if (p.K == 3) {
+        if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 1) launch_conv_p<3, 1>(p, in, out, wpk, bias, st);
+        else launch_conv_p<3, 0>(p, in, out, wpk, bias, st);
+    } else {
+        if (p.path == 2) launch_conv_p<1, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 1) launch_conv_p<1, 1>(p, in, out, wpk, bias, st);
+        else launch_conv_p<1, 0>(p, in, out, wpk, bias, st);
+    }
+}
+
+static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+static long packed_weight_elems(int C, int N, int K)
+{
+    return (long)((N + kTm - 1) / kTm) * ((C + kTn - 1) / kTn) * K * K * 128;
+}
+
+// ---------------------------------------------------------------------------- tier 1: driver state
+
+namespace {
+struct DriverState {
+    std::mutex mu;
+    int device = 0;
+    bool inited = false;
+    int qw = 0, qa_in = 0, qa_out = 0, qb = 0;
+    // grow-only scratch for the per-layer calls
+    void *in_items = nullptr, *out_items = nullptr, *wpk = nullptr, *bias_pk = nullptr;
+    size_t in_cap = 0, out_cap = 0, wpk_cap = 0, bias_cap = 0;
+    int *bound = nullptr;
+    struct HostBuf {
+        char *host;
+        char *dev;
+        size_t size;
+    };
+    std::vector<HostBuf> hostbufs;
+};
+DriverState g_drv;
+
+int ensure(void **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return YOLO2_SUCCESS;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    HIP_TRY(hipMalloc(p, need), YOLO2_MMAP_ERROR);
+    *cap = need;
+    return YOLO2_SUCCESS;
+}
+
+int sync_with_timeout(hipStream_t st, uint32_t timeout_ms)
+{
+    if (timeout_ms == 0) {  // 0 = wait forever (yolo2_accel_linux.h:55-61)
+        HIP_TRY(hipStreamSynchronize(st), YOLO2_ERROR);
+        return YOLO2_SUCCESS;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return YOLO2_SUCCESS;
+        if (e != hipErrorNotReady) return fail(YOLO2_ERROR, "stream error: %s", hipGetErrorString(e));
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (ms > (long long)timeout_ms) return fail(YOLO2_TIMEOUT, "layer did not finish within %u ms", timeout_ms);
+    }
+}
+
+// yolo2_accel_linux.c:383-414, which mirrors the HLS asserts (yolo2_accel.cpp:75-87)
+bool validate_conv_params(int ifm, int ofm, int k, int s, int iw, int ih, int ow, int oh, int pad, int tm, int tn,
+                          int tr, int tc)
+{
+    if (ifm <= 0 || ifm > 2048) return false;
+    if (ofm <= 0 || ofm > 2048) return false;
+    if (k <= 0 || k > 3) return false;
+    if (s <= 0 || s > 2) return false;
+    if (iw <= 0 || iw > 1024 || ih <= 0 || ih > 1024) return false;
+    if (ow <= 0 || ow > 1024 || oh <= 0 || oh > 1024) return false;
+    if (pad < 0 || pad > 4) return false;
+    if (tm <= 0 || tm > 32) return false;
+    if (tn < 0 || tn > 4) return false;
+    if (tr <= 0 || tr > 13) return false;
+    if (tc <= 0 || tc > 13) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" int yolo2_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int yolo2_hip_select_device(int device)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (device < 0 || device >= yolo2_hip_device_count()) return fail(YOLO2_INIT_ERROR, "no HIP device %d", device);
+    g_drv.device = device;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_accel_init(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (yolo2_hip_device_count() <= g_drv.device)
+        return fail(YOLO2_INIT_ERROR, "no HIP device available (the GPU path has no CPU fallback)");
+    HIP_TRY(hipSetDevice(g_drv.device), YOLO2_INIT_ERROR);
+    if (!g_drv.bound) HIP_TRY(hipMalloc((void **)&g_drv.bound, sizeof(int)), YOLO2_MMAP_ERROR);
+    g_drv.inited = true;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" void yolo2_accel_cleanup(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!g_drv.inited) return;
+    (void)hipDeviceSynchronize();
+    for (void *p : {g_drv.in_items, g_drv.out_items, g_drv.wpk, g_drv.bias_pk, (void *)g_drv.bound})
+        if (p) (void)hipFree(p);
+    g_drv.in_items = g_drv.out_items = g_drv.wpk = g_drv.bias_pk = nullptr;
+    g_drv.bound = nullptr;
+    g_drv.in_cap = g_drv.out_cap = g_drv.wpk_cap = g_drv.bias_cap = 0;
+    g_drv.inited = false;
+}
+
+extern "C" void yolo2_set_q_values(int32_t qw, int32_t qa_in, int32_t qa_out, int32_t qb)
+{
+    g_drv.qw = qw; g_drv.qa_in = qa_in; g_drv.qa_out = qa_out; g_drv.qb = qb;
+}
+extern "C" int yolo2_is_busy(void) { return hipStreamQuery(nullptr) == hipErrorNotReady ? 1 : 0; }
+extern "C" int yolo2_is_done(void) { return hipStreamQuery(nullptr) == hipSuccess ? 1 : 0; }
+extern "C" int yolo2_wait_for_completion(uint32_t timeout_ms) { return sync_with_timeout(nullptr, timeout_ms); }
+
+extern "C" int yolo2_hip_alloc(size_t bytes, uint64_t *dev_addr)
+{
+    void *p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes), YOLO2_MMAP_ERROR);
+    *dev_addr = (uint64_t)(uintptr_t)p;
+    return YOLO2_SUCCESS;
+}
+extern "C" void yolo2_hip_free(uint64_t dev_addr) { (void)hipFree((void *)(uintptr_t)dev_addr); }
+extern "C" int yolo2_hip_memcpy_h2d(uint64_t dst, const void *src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy((void *)(uintptr_t)dst, src, bytes, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    return YOLO2_SUCCESS;
+}
+extern "C" int yolo2_hip_memcpy_d2h(void *dst, uint64_t src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, (const void *)(uintptr_t)src, bytes, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    return YOLO2_SUCCESS;
+}
+extern "C" int yolo2_hip_memset(uint64_t dst, int value, size_t bytes)
+{
+    HIP_TRY(hipMemset((void *)(uintptr_t)dst, value, bytes), YOLO2_DMA_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+// dma_buffer_manager.h:94-139 on mapped pinned host memory: one set of pages, two addresses.
+extern "C" int memory_allocate_ddr(size_t size, size_t alignment, memory_buffer_t *buffer)
+{
+    (void)alignment;  // hipHostMalloc returns page-aligned memory (reference asks for 4 KiB)
+    if (!buffer || size == 0) return -1;
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, size, hipHostMallocMapped) != hipSuccess) return fail(-1, "hipHostMalloc(%zu) failed", size);
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+        (void)hipHostFree(h);
+        return fail(-1, "hipHostGetDevicePointer failed");
+    }
+    memset(h, 0, size);
+    buffer->ptr = h;
+    buffer->size = size;
+    buffer->phys_addr = (uint64_t)(uintptr_t)d;
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    g_drv.hostbufs.push_back({(char *)h, (char *)d, size});
+    return 0;
+}
+extern "C" void memory_free_ddr(memory_buffer_t *buffer)
+{
+    if (!buffer || !buffer->ptr) return;
+    {
+        std::lock_guard<std::mutex> lk(g_drv.mu);
+        auto &v = g_drv.hostbufs;
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const DriverState::HostBuf &b) { return b.host == buffer->ptr; }), v.end());
+    }
+    (void)hipHostFree(buffer->ptr);
+    buffer->ptr = nullptr;
+    buffer->size = 0;
+    buffer->phys_addr = 0;
+}
+extern "C" int memory_allocate_weights(size_t size, memory_buffer_t *b) { return memory_allocate_ddr(size, 4096, b); }
+extern "C" int memory_allocate_bias(size_t size, memory_buffer_t *b) { return memory_allocate_ddr(size, 4096, b); }
+extern "C" int memory_allocate_inference_buffer(memory_buffer_t *b)
+{
+    // MEM_LEN int16 words + the reference's 512-element guard bands (yolo2_config.h:99, yolo2_model.cpp:243-244)
+    return memory_allocate_ddr((size_t)(6922240 + 1024) * sizeof(int16_t), 4096, b);
+}
+extern "C" uint64_t memory_get_phys_addr(void *virt_addr)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    for (const auto &b : g_drv.hostbufs)
+        if ((char *)virt_addr >= b.host && (char *)virt_addr < b.host + b.size)
+            return (uint64_t)(uintptr_t)(b.dev + ((char *)virt_addr - b.host));
+    return 0;
+}
+extern "C" void memory_flush_cache(void *addr, size_t size) { (void)addr; (void)size; __sync_synchronize(); }
+extern "C" void memory_invalidate_cache(void *addr, size_t size) { (void)addr; (void)size; (void)hipDeviceSynchronize(); }
+
+// ---- per-layer calls
+
+static int max_abs_i16_dev(const short *dev, int n, int *out)
+{
+    std::vector<short> h(n);
+    HIP_TRY(hipMemcpy(h.data(), dev, (size_t)n * 2, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    int m = 0;
+    for (short v : h) m = std::max(m, std::abs((int)v));
+    *out = m;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
+                                        uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
+                                        int input_w, int input_h, int output_w, int output_h, int padding,
+                                        int is_nl, int is_bn, int tm, int tn, int tr, int tc, int ofm_num_bound,
+                                        int mloopsxTM, int mloops_a1xTM, int layer_type, int qw, int qa_in,
+                                        int qa_out, int qb, uint32_t timeout_ms)
+{
+    (void)is_bn; (void)ofm_num_bound; (void)mloopsxTM; (void)mloops_a1xTM;  // BN is pre-folded; tiling is internal
+    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    if (layer_type != 0) return fail(YOLO2_ERROR, "yolo2_execute_conv_layer: layer_type %d is not CONV", layer_type);
+    if (!input_addr || !output_addr || !weight_addr || !beta_addr) return fail(YOLO2_ERROR, "null buffer address");
+    if (!validate_conv_params(ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w, output_h, padding, tm, tn, tr, tc))
+        return fail(YOLO2_ERROR, "conv parameters outside the accelerator's limits");
+    if (output_w != (input_w - ksize + 2 * padding) / kstride + 1 || output_h != (input_h - ksize + 2 * padding) / kstride + 1)
+        return fail(YOLO2_ERROR, "output size does not match input/kernel/stride/padding");
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    hipStream_t st = nullptr;
+    const short *in = (const short *)(uintptr_t)input_addr;
+    short *out = (short *)(uintptr_t)output_addr;
+    const short *w = (const short *)(uintptr_t)weight_addr;
+    const short *beta = (const short *)(uintptr_t)beta_addr;
+    const int so = qa_in + qw - qa_out, sb = qb - qa_out;
+
+    const bool tiled = kstride == 1 && ((ksize == 3 && padding == 1) || (ksize == 1 && padding == 0));
+    if (!tiled) {
+        const int n = ofm_num * output_h * output_w;
+        hipLaunchKernelGGL(k_conv_ref_i16, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, w, beta, ifm_num, ofm_num,
+                           ksize, kstride, input_w, input_h, output_w, output_h, padding, is_nl ? 1 : 0, so, sb);
+        HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+        return sync_with_timeout(st, timeout_ms);
+    }
+
+    const ActGeom gi = make_geom(ifm_num, input_h, input_w, 1), go = make_geom(ofm_num, output_h, output_w, 1);
+    const long wpk_elems = packed_weight_elems(ifm_num, ofm_num, ksize);
+    const int MB = (ofm_num + 31) / 32;
+    int rc;
+    if ((rc = ensure(&g_drv.in_items, &g_drv.in_cap, (size_t)gi.items * 8))) return rc;
+    if ((rc = ensure(&g_drv.out_items, &g_drv.out_cap, (size_t)go.items * 8))) return rc;
+    if ((rc = ensure(&g_drv.wpk, &g_drv.wpk_cap, (size_t)wpk_elems * 2))) return rc;
+    if ((rc = ensure(&g_drv.bias_pk, &g_drv.bias_cap, (size_t)MB * 32 * 2))) return rc;
+    HIP_TRY(hipMemsetAsync(g_drv.in_items, 0, (size_t)gi.items * 8, st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemsetAsync(g_drv.bias_pk, 0, (size_t)MB * 32 * 2, st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemsetAsync(g_drv.bound, 0, sizeof(int), st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpyAsync(g_drv.bias_pk, beta, (size_t)ofm_num * 2, hipMemcpyDeviceToDevice, st), YOLO2_DMA_ERROR);
+    hipLaunchKernelGGL(k_ref_to_items, dim3(blocks_for((long)ifm_num * input_h * input_w, 256)), dim3(256), 0, st, in,
+                       (short *)g_drv.in_items, ifm_num, input_h, input_w, (input_w + 7) & ~7, gi.Wp, gi.cg_stride);
+    hipLaunchKernelGGL((k_repack_weights<short>), dim3(blocks_for(wpk_elems, 256)), dim3(256), 0, st, w, (short *)g_drv.wpk,
+                       ifm_num, ofm_num, ksize * ksize);
+    hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(wpk_elems / 4, 256), 1024)), dim3(256), 0, st,
+                       (const short *)g_drv.wpk, wpk_elems / 4, g_drv.bound);
+    int maxsum = 0, maxb = 0;
+    HIP_TRY(hipMemcpy(&maxsum, g_drv.bound, sizeof(int), hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    if ((rc = max_abs_i16_dev(beta, ofm_num, &maxb))) return rc;
+
+    ConvPlan p;
+    p.C = ifm_num; p.N = ofm_num; p.K = ksize; p.H = input_h; p.W = input_w; p.leaky = is_nl ? 1 : 0;
+    p.Qw = qw; p.Qa_in = qa_in; p.Qa_out = qa_out; p.Qb = qb;
+    p.path = choose_path(so, sb, maxsum, maxb);
+    plan_conv(p, gi, go.cg_stride, kLead, go.CG);
+    launch_conv(p, (const int2 *)g_drv.in_items, (int2 *)g_drv.out_items, (const int2 *)g_drv.wpk, (const short *)g_drv.bias_pk, st);
+    hipLaunchKernelGGL(k_items_to_ref, dim3(blocks_for((long)ofm_num * output_h * output_w, 256)), dim3(256), 0, st,
+                       (const short *)g_drv.out_items, out, ofm_num, output_h, output_w, (output_w + 7) & ~7, go.Wp, go.PL,
+                       go.cg_stride, 0);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return sync_with_timeout(st, timeout_ms);
+}
+
+extern "C" int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int channels, int ksize,
+                                           int kstride, int input_w, int input_h, int output_w, int output_h,
+                                           int padding, int tm, int tr, int tc, int ofm_num_bound, int mloopsxTM,
+                                           int mloops_a1xTM, uint32_t timeout_ms)
+{
+    (void)padding;  // forced to 0 by the scheduler (core_scheduler.cpp:72-73)
+    (void)ofm_num_bound; (void)mloopsxTM; (void)mloops_a1xTM;
+    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    if (!input_addr || !output_addr) return fail(YOLO2_ERROR, "null buffer address");
+    if (!validate_conv_params(channels, channels, ksize, kstride, input_w, input_h, output_w, output_h, 0, tm, 0, tr, tc))
+        return fail(YOLO2_ERROR, "maxpool parameters outside the accelerator's limits");
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    const int n = channels * output_h * output_w;
+    hipLaunchKernelGGL((k_pool_ref<short>), dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, (const short *)(uintptr_t)input_addr,
+                       (short *)(uintptr_t)output_addr, channels, ksize, kstride, input_w, input_h, output_w, output_h,
+                       (short)-32768);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return sync_with_timeout(nullptr, timeout_ms);
+}
+
+extern "C" int yolo2_execute_conv_layer_f32(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
+                                            uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
+                                            int input_w, int input_h, int output_w, int output_h, int padding,
+                                            int is_nl, uint32_t timeout_ms)
+{
+    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    if (!input_addr || !output_addr || !weight_addr || !beta_addr) return fail(YOLO2_ERROR, "null buffer address");
+    if (!validate_conv_params(ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w, output_h, padding, 1, 0, 1, 1))
+        return fail(YOLO2_ERROR, "conv parameters outside the accelerator's limits");
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    const int n = ofm_num * output_h * output_w;
+    hipLaunchKernelGGL(k_conv_ref_f32, dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, (const float *)(uintptr_t)input_addr,
+                       (float *)(uintptr_t)output_addr, (const float *)(uintptr_t)weight_addr,
+                       (const float *)(uintptr_t)beta_addr, ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w,
+                       output_h, padding, is_nl ? 1 : 0);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return sync_with_timeout(nullptr, timeout_ms);
+}
+
+// ---------------------------------------------------------------------------- tier 2: whole network
+
+struct Tensor {
+    ActGeom g;
+    int2 *d = nullptr;
+};
+
+struct yolo2_hip_ctx {
+    int device = 0;
+    bool weights_loaded = false;
+    short *wpk = nullptr;      // all layers, packed
+    short *bias_pk = nullptr;  // all layers, padded to 32
+    long wpk_off[YOLO2_N_CONV], bias_off[YOLO2_N_CONV];
+    int maxsum[YOLO2_N_CONV], maxbias[YOLO2_N_CONV];
+    std::vector<int> weight_q, bias_q, act_q;
+    ConvPlan plan[32];
+    int reorg_shift = 0, final_q = 0;
+    int batch = 0;
+    Tensor t_in, t_out[32], t_cat;
+    // per-layer device timing: a ring of event sets, one per profiled run (hipEvents on the
+    // stream the kernels are launched on); the analogue of yolo2_inference.c:75-142
+    static constexpr int kProfSlots = 32;
+    bool prof = false;
+    hipEvent_t ev[kProfSlots][33];
+    bool ev_made = false;
+    long prof_runs = 0;
+};
+
+extern "C" int yolo2_hip_create(int device, yolo2_hip_ctx **out)
+{
+    if (!out) return fail(YOLO2_ERROR, "null ctx pointer");
+    if (device < 0 || device >= yolo2_hip_device_count())
+        return fail(YOLO2_INIT_ERROR, "no HIP device %d (the GPU path has no CPU fallback)", device);
+    HIP_TRY(hipSetDevice(device), YOLO2_INIT_ERROR);
+    yolo2_hip_ctx *c = new (std::nothrow) yolo2_hip_ctx();
+    if (!c) return fail(YOLO2_ERROR, "out of host memory");
+    c->device = device;
+    *out = c;
+    return YOLO2_SUCCESS;
+}
+
+static void free_activations(yolo2_hip_ctx *c)
+{
+    if (c->t_in.d) (void)hipFree(c->t_in.d);
+    c->t_in.d = nullptr;
+    if (c->t_cat.d) (void)hipFree(c->t_cat.d);
+    c->t_cat.d = nullptr;
+    for (int i = 0; i < 32; ++i) {
+        if (c->t_out[i].d && i != 24 && i != 27) (void)hipFree(c->t_out[i].d);
+        c->t_out[i].d = nullptr;
+    }
+    c->batch = 0;
+}
+
+extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    free_activations(c);
+    if (c->wpk) (void)hipFree(c->wpk);
+    if (c->bias_pk) (void)hipFree(c->bias_pk);
+    if (c->ev_made)
+        for (auto &slot : c->ev)
+            for (auto &e : slot) (void)hipEventDestroy(e);
+    delete c;
+}
+
+// Resolve the per-layer Q values exactly like the layer loop does (yolo2_model.cpp:290-340, 379-399).
+static void resolve_q(yolo2_hip_ctx *c)
+{
+    const int na = (int)c->act_q.size();
+    int current_Qa = na ? c->act_q[0] : 0, route24_q = 0, pending = -1, ord = 0;
+    c->reorg_shift = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type == L_CONV) {
+            ConvPlan &p = c->plan[i];
+            p.C = l.c; p.N = l.n; p.K = l.size; p.H = l.h; p.W = l.w; p.leaky = l.leaky;
+            p.Qa_in = ord < na ? c->act_q[ord] : current_Qa;
+            p.Qa_out = ord + 1 < na ? c->act_q[ord + 1] : p.Qa_in;
+            p.Qw = ord < (int)c->weight_q.size() ? c->weight_q[ord] : 0;
+            p.Qb = ord < (int)c->bias_q.size() ? c->bias_q[ord] : 0;
+            if (pending >= 0) p.Qa_in = pending;
+            current_Qa = p.Qa_out;
+            if (i == 24) route24_q = current_Qa;
+            pending = -1;
+            p.path = choose_path(p.Qa_in + p.Qw - p.Qa_out, p.Qb - p.Qa_out, c->maxsum[ord], c->maxbias[ord]);
+            ord++;
+        } else if (l.type == L_REORG) {
+            if (route24_q > 0) {
+                const int target = std::min(route24_q, current_Qa);
+                c->reorg_shift = current_Qa - target;
+                if (c->reorg_shift != 0) current_Qa = target;
+                pending = current_Qa;
+            }
+        }
+    }
+    c->final_q = current_Qa;
+}
+
+static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, const short *b_dev, size_t n_bias,
+                       const int32_t *weight_q, int n_wq, const int32_t *bias_q, int n_bq, const int32_t *act_q, int n_aq)
+{
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights blob too small (%zu < %d)", n_weights, YOLO2_N_WEIGHTS);
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias blob too small (%zu < %d)", n_bias, YOLO2_N_BIAS);
+    if (n_wq < YOLO2_N_CONV || n_bq < YOLO2_N_CONV) return fail(YOLO2_ERROR, "Q tables too small for conv layers");
+    if (n_aq < 1) return fail(YOLO2_ERROR, "Activation Q table (iofm_Q.bin) is required for int16 inference.");
+    c->weight_q.assign(weight_q, weight_q + n_wq);
+    c->bias_q.assign(bias_q, bias_q + n_bq);
+    c->act_q.assign(act_q, act_q + n_aq);
+
+    long wtot = 0, btot = 0;
+    int ord = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            c->wpk_off[ord] = wtot;
+            c->bias_off[ord] = btot;
+            wtot += packed_weight_elems(kNet[i].c, kNet[i].n, kNet[i].size);
+            btot += (long)((kNet[i].n + 31) / 32) * 32;
+            ord++;
+        }
+    if (c->wpk) (void)hipFree(c->wpk);
+    if (c->bias_pk) (void)hipFree(c->bias_pk);
+    c->wpk = c->bias_pk = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->wpk, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&c->bias_pk, (size_t)btot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(c->bias_pk, 0, (size_t)btot * 2), YOLO2_DMA_ERROR);
+    int *bound = nullptr;
+    HIP_TRY(hipMalloc((void **)&bound, sizeof(int) * YOLO2_N_CONV), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(bound, 0, sizeof(int) * YOLO2_N_CONV), YOLO2_DMA_ERROR);
+    std::vector<short> hb(YOLO2_N_BIAS);
+    HIP_TRY(hipMemcpy(hb.data(), b_dev, (size_t)YOLO2_N_BIAS * 2, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    long woff = 0, boff = 0;
+    ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type != L_CONV) continue;
+        const long n = packed_weight_elems(l.c, l.n, l.size);
+        hipLaunchKernelGGL((k_repack_weights<short>), dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, w_dev + woff,
+                           c->wpk + c->wpk_off[ord], l.c, l.n, l.size * l.size);
+        hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(n / 4, 256), 1024)), dim3(256), 0, nullptr,
+                           (const short *)(c->wpk + c->wpk_off[ord]), n / 4, bound + ord);
+        HIP_TRY(hipMemcpyAsync(c->bias_pk + c->bias_off[ord], b_dev + boff, (size_t)l.n * 2, hipMemcpyDeviceToDevice, nullptr),
+                YOLO2_DMA_ERROR);
+        int mb = 0;
+        for (int k = 0; k < l.n; ++k) mb = std::max(mb, std::abs((int)hb[boff + k]));
+        c->maxbias[ord] = mb;
+        woff += yolo2_weight_len[ord];
+        boff += yolo2_bias_len[ord];
+        ord++;
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    HIP_TRY(hipMemcpy(c->maxsum, bound, sizeof(int) * YOLO2_N_CONV, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    (void)hipFree(bound);
+    resolve_q(c);
+    c->weights_loaded = true;
+    if (c->batch) {  // re-plan for the new Q values
+        const int b = c->batch;
+        c->batch = 0;
+        return yolo2_hip_set_batch(c, b);
+    }
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *c, uint64_t weights_reorg_dev, size_t n_weights,
+                                                uint64_t bias_dev, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                                const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!weights_reorg_dev || !bias_dev || !weight_q || !bias_q || !act_q) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    return load_common(c, (const short *)(uintptr_t)weights_reorg_dev, n_weights, (const short *)(uintptr_t)bias_dev, n_bias,
+                       weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
+}
+
+extern "C" int yolo2_hip_load_weights_int16(yolo2_hip_ctx *c, const int16_t *weights_reorg, size_t n_weights,
+                                            const int16_t *bias, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                            const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!weights_reorg || !bias || !weight_q || !bias_q || !act_q) return fail(YOLO2_ERROR, "null argument");
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    short *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 2, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 2, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    const int rc = load_common(c, wd, YOLO2_N_WEIGHTS, bd, YOLO2_N_BIAS, weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(wd);
+    (void)hipFree(bd);
+    return rc;
+}
+
+extern "C" int yolo2_hip_layer_path(yolo2_hip_ctx *c, int ord)
+{
+    if (!c || !c->weights_loaded || ord < 0 || ord >= YOLO2_N_CONV) return -1;
+    int o = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            if (o == ord) return c->plan[i].path;
+            o++;
+        }
+    return -1;
+}
+
+static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
+{
+    t.g = make_geom(C, H, W, B);
+    HIP_TRY(hipMalloc((void **)&t.d, (size_t)t.g.items * 8), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(t.d, 0, (size_t)t.g.items * 8), YOLO2_DMA_ERROR);  // the zeros ARE the conv padding
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "load weights before set_batch");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    if (c->batch != batch) {
+        free_activations(c);
+        int rc;
+        if ((rc = alloc_tensor(c->t_in, 3, 416, 416, batch))) return rc;
+        if ((rc = alloc_tensor(c->t_cat, 1280, 13, 13, batch))) return rc;
+        for (int i = 0; i < 31; ++i) {
+            const LayerDesc &l = kNet[i];
+            if (l.type == L_CONV && i != 24) {
+                if ((rc = alloc_tensor(c->t_out[i], l.n, l.h, l.w, batch))) return rc;
+            } else if (l.type == L_MAX) {
+                if ((rc = alloc_tensor(c->t_out[i], l.c, l.h / 2, l.w / 2, batch))) return rc;
+            }
+        }
+        c->t_out[24] = c->t_cat;  // conv-24 output and the reorg output live in the concat tensor
+        c->t_out[27] = c->t_cat;  // (yolo2_model.cpp:97-104 does the same by arena placement)
+        c->batch = batch;
+    }
+    for (int i = 0; i < 32; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+        const Tensor &tout = c->t_out[i];
+        const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
+        const int CGout = (kNet[i].n + 3) / 4;
+        plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
+    }
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (enable && !c->ev_made) {
+        for (auto &slot : c->ev)
+            for (auto &e : slot) HIP_TRY(hipEventCreate(&e), YOLO2_ERROR);
+        c->ev_made = true;
+    }
+    c->prof = enable != 0;
+    c->prof_runs = 0;  // (re)start the averaging window
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_layer_times_ms(yolo2_hip_ctx *c, float *ms32)
+{
+    if (!c || !ms32) return fail(YOLO2_ERROR, "null argument");
+    if (c->prof_runs == 0) return fail(YOLO2_ERROR, "no profiled run yet");
+    const int n = (int)std::min<long>(c->prof_runs, yolo2_hip_ctx::kProfSlots);
+    for (int i = 0; i < 32; ++i) ms32[i] = 0.f;
+    for (int sidx = 0; sidx < n; ++sidx) {
+        HIP_TRY(hipEventSynchronize(c->ev[sidx][32]), YOLO2_ERROR);
+        for (int i = 0; i < 32; ++i) {
+            float t = 0;
+            HIP_TRY(hipEventElapsedTime(&t, c->ev[sidx][i], c->ev[sidx][i + 1]), YOLO2_ERROR);
+            ms32[i] += t / n;
+        }
+    }
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x, int *grid_y, int *block, int *lds_bytes,
+                                          int *ppl)
+{
+    if (!c || !c->batch) return fail(YOLO2_ERROR, "set_batch first");
+    int o = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            if (o == ord) {
+                if (grid_x) *grid_x = c->plan[i].grid.x;
+                if (grid_y) *grid_y = c->plan[i].grid.y;
+                if (block) *block = 256;
+                if (lds_bytes) *lds_bytes = c->plan[i].lds_bytes;
+                if (ppl) *ppl = c->plan[i].P;
+                return YOLO2_SUCCESS;
+            }
+            o++;
+        }
+    return fail(YOLO2_ERROR, "bad conv ordinal %d", ord);
+}
+
+extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, int batch, uint64_t region_dev,
+                                         int *final_q, void *stream)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "weights not loaded");
+    if (!frames_dev || !region_dev) return fail(YOLO2_ERROR, "null buffer address");
+    if (batch != c->batch) {
+        const int rc = yolo2_hip_set_batch(c, batch);
+        if (rc) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const float *frames = (const float *)(uintptr_t)frames_dev;
+    short *region = (short *)(uintptr_t)region_dev;
+    const int B = batch;
+    const float scale = ldexpf(1.0f, c->act_q[0]);
+
+    hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    {  // input quantise + pack (yolo2_model.cpp:257-278); its time is booked to layer 0
+        const ActGeom &g = c->t_in.g;
+        hipLaunchKernelGGL(k_pack_input, dim3(blocks_for((long)B * g.H * g.W, 256)), dim3(256), 0, st, frames, c->t_in.d, B,
+                           g.H, g.W, g.Wp, g.PL, scale);
+    }
+    int ord = 0;
+    const Tensor *cur = &c->t_in;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        switch (l.type) {
+        case L_CONV: {
+            const Tensor *tin = i == 26 ? &c->t_out[16] : (i == 29 ? &c->t_cat : cur);
+            launch_conv(c->plan[i], tin->d, c->t_out[i].d, (const int2 *)(c->wpk + c->wpk_off[ord]),
+                        c->bias_pk + c->bias_off[ord], st);
+            cur = &c->t_out[i];
+            ord++;
+            break;
+        }
+        case L_MAX: {
+            const ActGeom &gi = cur->g, &go = c->t_out[i].g;
+            const long n = (long)go.CG * B * go.H * go.W;
+            hipLaunchKernelGGL(k_maxpool2, dim3(blocks_for(n, 256)), dim3(256), 0, st, cur->d, c->t_out[i].d, go.CG, B, go.H,
+                               go.W, gi.Wp, gi.PL, go.Wp, go.PL);
+            cur = &c->t_out[i];
+            break;
+        }
+        case L_REORG: {
+            const ActGeom &gi = cur->g, &go = c->t_cat.g;
+            hipLaunchKernelGGL(k_reorg, dim3(blocks_for((long)B * 256 * 169, 256)), dim3(256), 0, st, (const short *)cur->d,
+                               (short *)c->t_cat.d, B, gi.Wp, gi.PL, gi.cg_stride, go.Wp, go.PL, go.cg_stride, c->reorg_shift);
+            cur = &c->t_cat;
+            break;
+        }
+        case L_ROUTE:
+            break;  // concat by placement (yolo2_model.cpp:404-405)
+        case L_REGION: {
+            const ActGeom &g = cur->g;
+            hipLaunchKernelGGL(k_unpack_dense, dim3(blocks_for((long)B * 425 * 169, 256)), dim3(256), 0, st,
+                               (const short *)cur->d, region, B, 425, 13, 13, g.Wp, g.PL, g.cg_stride);
+            break;
+        }
+        }
+        if (ev) (void)hipEventRecord(ev[i + 1], st);
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    if (ev) c->prof_runs++;
+    if (final_q) *final_q = c->final_q;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_batch_int16_host(yolo2_hip_ctx *c, const float *frames, int batch, int16_t *region,
+                                              int *final_q)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    float *fd = nullptr;
+    short *rd = nullptr;
+    HIP_TRY(hipMalloc((void **)&fd, (size_t)batch * YOLO2_FRAME_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&rd, (size_t)batch * YOLO2_REGION_ELEMS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(fd, frames, (size_t)batch * YOLO2_FRAME_ELEMS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    int rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)fd, batch, (uint64_t)(uintptr_t)rd, final_q, nullptr);
+    if (rc == YOLO2_SUCCESS) {
+        hipError_t e = hipMemcpy(region, rd, (size_t)batch * YOLO2_REGION_ELEMS * 2, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(YOLO2_DMA_ERROR, "D2H of region tensor failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(fd);
+    (void)hipFree(rd);
+    return rc;
+}
+
+extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int frame, int16_t *out, size_t cap,
+                                            size_t *out_elems)
+{
+    if (!c || !out) return fail(YOLO2_ERROR, "null argument");
+    if (layer_idx < 0 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
+    const LayerDesc &l = kNet[layer_idx];
+    if (l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
+    const Tensor &t = c->t_out[layer_idx];
+    int C = l.type == L_MAX ? l.c : l.n, H = t.g.H, W = t.g.W;
+    const short *base = (const short *)t.d;
+    if (layer_idx == 24) base += (long)64 * t.g.cg_stride * 4;  // channels 256.. of the concat tensor
+    const int W8 = (W + 7) & ~7;
+    const size_t n = (size_t)C * H * W8;
+    if (out_elems) *out_elems = n;
+    if (cap < n) return fail(YOLO2_ERROR, "output buffer too small (%zu < %zu)", cap, n);
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    short *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, n * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(tmp, 0, n * 2), YOLO2_DMA_ERROR);
+    hipLaunchKernelGGL(k_items_to_ref, dim3(blocks_for((long)C * H * W, 256)), dim3(256), 0, nullptr, base, tmp, C, H, W, W8,
+                       t.g.Wp, t.g.PL, t.g.cg_stride, frame);
+    hipError_t e = hipMemcpy(out, tmp, n * 2, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(YOLO2_DMA_ERROR, "D2H failed: %s", hipGetErrorString(e));
+    return YOLO2_SUCCESS;
+}

@@ -1,0 +1,52 @@
+"""Frame sharding across GPUs: frames are independent, so the only collective is
+ONE broadcast of the weight blobs at init (RCCL over xGMI when the backend is nccl); there are
+no steady-state collectives.  Works on any torch.distributed backend (gloo in the CPU tests)."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import net
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous frame range [lo, hi) of `rank`; sizes differ by at most one."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def pack_q_tables(weight_q, bias_q, act_q) -> torch.Tensor:
+    """[n_wq, n_bq, n_aq, values...] as one int32 tensor of fixed length 3 + 3*64."""
+    t = torch.zeros(3 + 3 * 64, dtype=torch.int32)
+    for i, q in enumerate((weight_q, bias_q, act_q)):
+        q = np.asarray(q, dtype=np.int32)
+        assert q.size <= 64
+        t[i] = q.size
+        t[3 + 64 * i: 3 + 64 * i + q.size] = torch.from_numpy(q.copy())
+    return t
+
+
+def unpack_q_tables(t: torch.Tensor):
+    t = t.cpu().numpy()
+    return tuple(t[3 + 64 * i: 3 + 64 * i + int(t[i])].astype(np.int32) for i in range(3))
+
+
+def broadcast_model(model, device: torch.device, src: int = 0):
+    """Rank `src` holds a SynthModel (others pass None).  Returns (weights int16 tensor on
+    `device`, bias int16 tensor, weight_q, bias_q, act_q) on every rank."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        w = torch.from_numpy(model.weights_i16()).to(device)
+        b = torch.from_numpy(model.bias_i16()).to(device)
+        q = pack_q_tables(model.weight_q, model.bias_q, model.act_q).to(device)
+    else:
+        w = torch.empty(net.N_WEIGHTS, dtype=torch.int16, device=device)
+        b = torch.empty(net.N_BIAS, dtype=torch.int16, device=device)
+        q = torch.empty(3 + 3 * 64, dtype=torch.int32, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        # byte views: gloo (CPU tests) has no int16 collectives; on nccl (= RCCL) it is the same copy
+        dist.broadcast(w.view(torch.uint8), src)   # 101,883,584 B: the one large collective of the job
+        dist.broadcast(b.view(torch.uint8), src)
+        dist.broadcast(q, src)
+    wq, bq, aq = unpack_q_tables(q)
+    return w, b, wq, bq, aq

@@ -1,0 +1,265 @@
+"""ctypes binding of libyolo2_hip.so (include/yolo2_hip.h).
+
+This is host plumbing only: every compute call goes through the C ABI into the hand-written
+HIP kernels.  There is no CPU fallback: if the library is missing or no GPU is present the
+calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import net
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libyolo2_hip.so")
+
+YOLO2_SUCCESS, YOLO2_ERROR, YOLO2_TIMEOUT, YOLO2_INIT_ERROR, YOLO2_MMAP_ERROR, YOLO2_DMA_ERROR = 0, -1, -2, -3, -4, -5
+
+EXPORTS = [
+    "yolo2_accel_init", "yolo2_accel_cleanup", "yolo2_hip_select_device", "yolo2_hip_device_count",
+    "yolo2_hip_last_error", "yolo2_set_q_values", "yolo2_is_busy", "yolo2_is_done", "yolo2_wait_for_completion",
+    "yolo2_execute_conv_layer", "yolo2_execute_maxpool_layer", "yolo2_execute_conv_layer_f32",
+    "memory_allocate_ddr", "memory_free_ddr", "memory_allocate_weights", "memory_allocate_bias",
+    "memory_allocate_inference_buffer", "memory_get_phys_addr", "memory_flush_cache", "memory_invalidate_cache",
+    "yolo2_hip_alloc", "yolo2_hip_free", "yolo2_hip_memcpy_h2d", "yolo2_hip_memcpy_d2h", "yolo2_hip_memset",
+    "yolo2_hip_create", "yolo2_hip_destroy", "yolo2_hip_load_weights_int16", "yolo2_hip_load_weights_int16_dev",
+    "yolo2_hip_layer_path", "yolo2_hip_set_batch", "yolo2_hip_run_batch_int16", "yolo2_hip_run_batch_int16_host",
+    "yolo2_hip_debug_layer_output", "yolo2_hip_set_profiling", "yolo2_hip_layer_times_ms",
+    "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
+]
+
+
+class Yolo2HipError(RuntimeError):
+    pass
+
+
+def build(force: bool = False) -> str:
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(PKG_DIR, "csrc", f) for f in os.listdir(os.path.join(PKG_DIR, "csrc"))]
+    srcs.append(os.path.join(os.path.dirname(PKG_DIR), "include", "yolo2_hip.h"))
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.run(["make", "-s", "-C", PKG_DIR], check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Yolo2HipError(f"{LIB_PATH} is missing: build it with `make -C {PKG_DIR}` "
+                            "(the GPU path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    u64, i32, u32, vp = C.c_uint64, C.c_int, C.c_uint32, C.c_void_p
+    L.yolo2_hip_last_error.restype = C.c_char_p
+    L.yolo2_execute_conv_layer.argtypes = [u64] * 4 + [i32] * 23 + [u32]
+    L.yolo2_execute_maxpool_layer.argtypes = [u64] * 2 + [i32] * 14 + [u32]
+    L.yolo2_execute_conv_layer_f32.argtypes = [u64] * 4 + [i32] * 10 + [u32]
+    L.yolo2_hip_alloc.argtypes = [C.c_size_t, C.POINTER(u64)]
+    L.yolo2_hip_free.argtypes = [u64]
+    L.yolo2_hip_memcpy_h2d.argtypes = [u64, vp, C.c_size_t]
+    L.yolo2_hip_memcpy_d2h.argtypes = [vp, u64, C.c_size_t]
+    L.yolo2_hip_memset.argtypes = [u64, i32, C.c_size_t]
+    L.yolo2_hip_create.argtypes = [i32, C.POINTER(vp)]
+    L.yolo2_hip_destroy.argtypes = [vp]
+    L.yolo2_hip_load_weights_int16.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32]
+    L.yolo2_hip_load_weights_int16_dev.argtypes = [vp, u64, C.c_size_t, u64, C.c_size_t, vp, i32, vp, i32, vp, i32]
+    L.yolo2_hip_layer_path.argtypes = [vp, i32]
+    L.yolo2_hip_set_batch.argtypes = [vp, i32]
+    L.yolo2_hip_run_batch_int16.argtypes = [vp, u64, i32, u64, C.POINTER(i32), vp]
+    L.yolo2_hip_run_batch_int16_host.argtypes = [vp, vp, i32, vp, C.POINTER(i32)]
+    L.yolo2_hip_debug_layer_output.argtypes = [vp, i32, i32, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.yolo2_hip_set_profiling.argtypes = [vp, i32]
+    L.yolo2_hip_layer_times_ms.argtypes = [vp, vp]
+    L.yolo2_hip_conv_launch_info.argtypes = [vp, i32] + [C.POINTER(i32)] * 5
+    L.yolo2_strip_int16_layer_pad.argtypes = [vp, C.c_size_t, vp, i32, vp]
+    L.yolo2_strip_int16_layer_pad.restype = C.c_long
+    L.memory_get_phys_addr.restype = u64
+    L.memory_get_phys_addr.argtypes = [vp]
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ""):
+    if rc != YOLO2_SUCCESS:
+        raise Yolo2HipError(f"{what} failed with status {rc}: {lib().yolo2_hip_last_error().decode()}")
+
+
+# ------------------------------------------------------------------ tier 1 helpers (tests)
+
+class DevBuf:
+    """HBM buffer holding a numpy array (the analogue of a udmabuf + its physical address)."""
+
+    def __init__(self, arr: np.ndarray = None, nbytes: int = None, fill: int = 0):
+        self.nbytes = arr.nbytes if arr is not None else nbytes
+        a = C.c_uint64(0)
+        check(lib().yolo2_hip_alloc(max(self.nbytes, 16), C.byref(a)), "yolo2_hip_alloc")
+        self.addr = a.value
+        if arr is not None:
+            arr = np.ascontiguousarray(arr)
+            check(lib().yolo2_hip_memcpy_h2d(self.addr, arr.ctypes.data_as(C.c_void_p), arr.nbytes), "h2d")
+        else:
+            check(lib().yolo2_hip_memset(self.addr, fill, self.nbytes), "memset")
+
+    def get(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(lib().yolo2_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), self.addr, out.nbytes), "d2h")
+        return out
+
+    def free(self):
+        if self.addr:
+            lib().yolo2_hip_free(self.addr)
+            self.addr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def w8(w):
+    return (w + 7) // 8 * 8
+
+
+def conv_layer_i16(x, w_reorg, bias, C_, N, K, stride, W, H, pad, leaky, Qw, Qa_in, Qa_out, Qb, fill=0):
+    """Calls yolo2_execute_conv_layer the way linux_app/src/yolo2_inference.c:371-381 does."""
+    OW = (W - K + 2 * pad) // stride + 1
+    OH = (H - K + 2 * pad) // stride + 1
+    TR = min(min((27 - K) // stride + 1, 13), OH)
+    TC = min(min((27 - K) // stride + 1, 13), OW)
+    TM, TN = min(N, 32), min(C_, 4)
+    mLoops = -(-N // TM)
+    bx, bw, bb = DevBuf(x), DevBuf(w_reorg), DevBuf(bias)
+    out0 = np.full((N, OH, w8(OW)), fill, dtype=np.int16)
+    by = DevBuf(out0)
+    rc = lib().yolo2_execute_conv_layer(bx.addr, by.addr, bw.addr, bb.addr, C_, N, K, stride, W, H, OW, OH, pad,
+                                        int(leaky), 0, TM, TN, TR, TC, (mLoops + 1) * TM, mLoops * TM,
+                                        (mLoops + 1) * TM, 0, Qw, Qa_in, Qa_out, Qb, 60000)
+    check(rc, "yolo2_execute_conv_layer")
+    y = by.get(np.int16, (N, OH, w8(OW)))
+    for b in (bx, bw, bb, by):
+        b.free()
+    return y
+
+
+def conv_layer_f32(x, w_reorg, bias, C_, N, K, stride, W, H, pad, leaky):
+    OW = (W - K + 2 * pad) // stride + 1
+    OH = (H - K + 2 * pad) // stride + 1
+    bx, bw, bb = DevBuf(x), DevBuf(w_reorg), DevBuf(bias)
+    by = DevBuf(np.zeros((N, OH, w8(OW)), dtype=np.float32))
+    check(lib().yolo2_execute_conv_layer_f32(bx.addr, by.addr, bw.addr, bb.addr, C_, N, K, stride, W, H, OW, OH,
+                                             pad, int(leaky), 60000), "yolo2_execute_conv_layer_f32")
+    y = by.get(np.float32, (N, OH, w8(OW)))
+    for b in (bx, bw, bb, by):
+        b.free()
+    return y
+
+
+def maxpool_layer_i16(x, C_, W, H, K=2, stride=2):
+    OW, OH = W // stride, H // stride
+    TR = min((27 - K) // stride + 1, 13, OH)
+    TC = min((27 - K) // stride + 1, 13, OW)
+    TM = min(4, C_)
+    mLoops = -(-C_ // TM)
+    bx = DevBuf(x)
+    by = DevBuf(np.zeros((C_, OH, w8(OW)), dtype=np.int16))
+    check(lib().yolo2_execute_maxpool_layer(bx.addr, by.addr, C_, K, stride, W, H, OW, OH, 1, TM, TR, TC,
+                                            (mLoops + 2) * TM, mLoops * TM, (mLoops + 1) * TM, 60000),
+          "yolo2_execute_maxpool_layer")
+    y = by.get(np.int16, (C_, OH, w8(OW)))
+    bx.free(); by.free()
+    return y
+
+
+# ------------------------------------------------------------------ tier 2: whole network
+
+class Yolo2Hip:
+    """One accelerator context on one GPU (yolo2_hip_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p(0)
+        check(lib().yolo2_hip_create(device, C.byref(self._h)), "yolo2_hip_create")
+        self.device = device
+        self.final_q = None
+
+    def close(self):
+        if self._h:
+            lib().yolo2_hip_destroy(self._h)
+            self._h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, weights_i16, bias_i16, weight_q, bias_q, act_q):
+        w = np.ascontiguousarray(weights_i16, dtype=np.int16)
+        b = np.ascontiguousarray(bias_i16, dtype=np.int16)
+        wq, bq, aq = (np.ascontiguousarray(a, dtype=np.int32) for a in (weight_q, bias_q, act_q))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().yolo2_hip_load_weights_int16(self._h, vp(w), w.size, vp(b), b.size, vp(wq), wq.size,
+                                                 vp(bq), bq.size, vp(aq), aq.size), "yolo2_hip_load_weights_int16")
+
+    def load_weights_dev(self, w_ptr, n_w, b_ptr, n_b, weight_q, bias_q, act_q):
+        wq, bq, aq = (np.ascontiguousarray(a, dtype=np.int32) for a in (weight_q, bias_q, act_q))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().yolo2_hip_load_weights_int16_dev(self._h, w_ptr, n_w, b_ptr, n_b, vp(wq), wq.size, vp(bq),
+                                                     bq.size, vp(aq), aq.size), "yolo2_hip_load_weights_int16_dev")
+
+    def load_model(self, model):
+        self.load_weights(model.weights_i16(), model.bias_i16(), model.weight_q, model.bias_q, model.act_q)
+
+    def layer_paths(self):
+        return [lib().yolo2_hip_layer_path(self._h, o) for o in range(len(net.CONVS))]
+
+    def set_batch(self, batch: int):
+        check(lib().yolo2_hip_set_batch(self._h, batch), "yolo2_hip_set_batch")
+
+    def run_batch_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0) -> int:
+        """Device pointers in/out; enqueues on `stream` and returns without synchronising."""
+        q = C.c_int(0)
+        check(lib().yolo2_hip_run_batch_int16(self._h, frames_ptr, batch, region_ptr, C.byref(q),
+                                              C.c_void_p(stream)), "yolo2_hip_run_batch_int16")
+        self.final_q = q.value
+        return q.value
+
+    def run_batch_host(self, frames: np.ndarray):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        B = frames.shape[0]
+        region = np.empty((B, 425, 13, 13), dtype=np.int16)
+        q = C.c_int(0)
+        check(lib().yolo2_hip_run_batch_int16_host(self._h, frames.ctypes.data_as(C.c_void_p), B,
+                                                   region.ctypes.data_as(C.c_void_p), C.byref(q)),
+              "yolo2_hip_run_batch_int16_host")
+        self.final_q = q.value
+        return region, q.value
+
+    def debug_layer_output(self, layer_idx: int, frame: int = 0) -> np.ndarray:
+        l = net.LAYERS[layer_idx]
+        shape = (l.out_c, l.out_h, w8(l.out_w))
+        out = np.empty(shape, dtype=np.int16)
+        n = C.c_size_t(0)
+        check(lib().yolo2_hip_debug_layer_output(self._h, layer_idx, frame, out.ctypes.data_as(C.c_void_p),
+                                                 out.size, C.byref(n)), "yolo2_hip_debug_layer_output")
+        assert n.value == out.size
+        return out
+
+    def set_profiling(self, on: bool):
+        check(lib().yolo2_hip_set_profiling(self._h, int(on)), "yolo2_hip_set_profiling")
+
+    def layer_times_ms(self) -> np.ndarray:
+        ms = np.zeros(32, dtype=np.float32)
+        check(lib().yolo2_hip_layer_times_ms(self._h, ms.ctypes.data_as(C.c_void_p)), "yolo2_hip_layer_times_ms")
+        return ms
+
+    def conv_launch_info(self, ord_: int):
+        v = [C.c_int(0) for _ in range(5)]
+        check(lib().yolo2_hip_conv_launch_info(self._h, ord_, *[C.byref(x) for x in v]), "conv_launch_info")
+        return dict(zip(("grid_x", "grid_y", "block", "lds_bytes", "pixels_per_lane"), (x.value for x in v)))
