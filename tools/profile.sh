@@ -1,5 +1,5 @@
 #!/bin/bash
-# Usage (on the GPU box, via gpurun):  bash tools_profile.sh <tag> [bench args...]
+# Usage (on the GPU box, via gpurun):  bash tools/profile.sh <tag> [bench args...]
 # Writes rocprofv3 kernel-trace stats of bench.py under gpurun_out/prof_<tag>/ and a compact
 # summary to gpurun_out/prof_<tag>_summary.txt (copy that into profiles/ to have it judged).
 set -e

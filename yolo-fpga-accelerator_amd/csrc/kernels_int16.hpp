@@ -9,8 +9,8 @@
 //   out = leaky ? (acc<0 ? acc/10 : acc) : acc
 // The per-(group,tap) round+saturate makes this an integer-VALU problem, not a GEMM: there is
 // no int16 MFMA on CDNA4 and a wider contraction would change results.  The kernel is built
-// around the 5-instruction step  v_dot2 / v_dot2 / v_ashrrev / v_add / v_med3  per
-// (4 channels x 1 tap x 1 output) with every operand already in registers:
+// around the per-(4 channels x 1 tap x 1 output) step (forms A/B below) with every operand
+// already in registers:
 //   * weights are wave-uniform -> scalar loads (s_load_dwordx16 per tap), SGPR operands;
 //   * the input tile of one channel group is staged once per workgroup in LDS and shared by
 //     the 4 wavefronts, each of which owns 8 of the workgroup's 32 output channels;
@@ -55,45 +55,20 @@ __device__ __forceinline__ int clamp16(int v) { return min(max(v, -32768), 32767
 
 // ---- the requantise-and-saturate step, 32-bit forms ------------------------------------------
 //
-// Form A (always valid under the int32 bound): for the 8 output channels of a wavefront and one
-// (pixel, tap):  t[m] = (dot4(w[m], x) + round) >> shift, then acc = med3(acc + t) in C++.
-// 3 instructions per step here + 2 outside = 5 per step.  Written as ONE asm statement because
-//  * hipcc's sdot2 builtin selects the VOP2 v_dot2c form and adds a v_mov per step to seed the
-//    accumulator; the VOP3P v_dot2_i32_i16 takes the rounding constant as src2 for free;
-//  * gfx950 needs wait states between a DOT result and a different VALU reading it, which hipcc
-//    does not pad inside/after asm (cdna_hip_programming.md 5.7 item 2).  The order below keeps
-//    every dependent pair 8 instructions apart, so no s_nop is needed at all.
-// Operands: w = SGPRs (one constant-bus read per instruction), x/r = VGPRs, shift = SGPR.
-__device__ __forceinline__ void dot8_shift(int (&t)[8], const int2 x, const int2 (&w)[8], const int r, const int s)
+// Issue cost on gfx950 (profiles/r01_ubench_valu_issue_cost.txt): v_dot2*, shifts, v_med3,
+// v_and_or take 4 SIMD cycles per wave64; v_add_u32 (VGPR operands), v_mov, v_and/or take 2.
+//
+// Form A (valid whenever no intermediate leaves int32): t = (dot4(w,x) + round) >> shift,
+// acc = med3(acc + t).  hipcc's sdot2 builtin selects the VOP2 v_dot2c form, which accumulates in
+// place, so the rounding constant is seeded with a (2-cycle) v_mov: 2+4+4+4+2+4 = 20 cycles/step.
+// The VOP3P v_dot2_i32_i16 would take the constant as src2 (18 cycles) but is only reachable
+// through inline asm, which hipcc can neither pad for the DOT->VALU wait states of gfx950 nor
+// schedule -- it spilled hundreds of VGPRs around such blocks -- so the builtin form is used.
+__device__ __forceinline__ int stepA(int acc, const int2 x, const int2 w, const int r, const int s)
 {
-    asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
-        "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
-        "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
-        "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
-        "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
-        "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
-        "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
-        "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
-        "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
-        "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
-        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
-        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
-        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
-        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
-        "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
-        "v_dot2_i32_i16 %7, %23, %25, %7\n\t"
-        "v_ashrrev_i32 %0, %27, %0\n\t"
-        "v_ashrrev_i32 %1, %27, %1\n\t"
-        "v_ashrrev_i32 %2, %27, %2\n\t"
-        "v_ashrrev_i32 %3, %27, %3\n\t"
-        "v_ashrrev_i32 %4, %27, %4\n\t"
-        "v_ashrrev_i32 %5, %27, %5\n\t"
-        "v_ashrrev_i32 %6, %27, %6\n\t"
-        "v_ashrrev_i32 %7, %27, %7"
-        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7])
-        : "s"(w[0].x), "s"(w[1].x), "s"(w[2].x), "s"(w[3].x), "s"(w[4].x), "s"(w[5].x), "s"(w[6].x), "s"(w[7].x),
-          "s"(w[0].y), "s"(w[1].y), "s"(w[2].y), "s"(w[3].y), "s"(w[4].y), "s"(w[5].y), "s"(w[6].y), "s"(w[7].y),
-          "v"(x.x), "v"(x.y), "v"(r), "s"(s));
+    int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w.x), r, false);
+    d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w.y), d, false);
+    return clamp16(acc + (d >> s));
 }
 
 // Form B (4 instructions per step, needs the tighter bound checked by the host): keep the
@@ -148,8 +123,9 @@ __device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
 // MODE 0: 32-bit form A, valid when the host proved no intermediate leaves int32.
 // MODE 1: 32-bit form B (pre-shifted accumulator), tighter bound, 4 instructions per step.
 // MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
-template <int KS, int P, int MODE>
-__global__ __launch_bounds__(256) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
+// NST: staging registers per thread, 256*NST >= LDS tile items.
+template <int KS, int P, int MODE, int NST>
+__global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                    const int2 *__restrict__ wpk,
                                                    const short *__restrict__ bias, const ConvArgs a)
 {
@@ -211,15 +187,38 @@ __global__ __launch_bounds__(256) void k_conv_i16(const int2 *__restrict__ in, i
     // Form B wants v_and_or_b32 (mask in an SGPR, round in a VGPR: one constant-bus operand);
     // hide the uniformity of `round` so hipcc keeps it in a VGPR instead of splitting and/or.
     int r_vgpr = r;
-    if (MODE == 1) asm volatile("" : "+v"(r_vgpr));
+    if (MODE != 2) asm volatile("" : "+v"(r_vgpr));
     const char *lds_b = reinterpret_cast<const char *>(lds);
     const int2 *src = in + kLead + tile_start;
     const int2 *wq = wpk + ((long)mb * a.CGin * KK * 32 + wave * 8);
 
+    // Input tiles are double-buffered in LDS: the global loads of group cg+1 are issued before the
+    // compute on group cg and written to the other buffer after it, so HBM/L2 latency hides behind
+    // ~KK*P*8 requant steps and there is ONE barrier per channel group.
+    int2 stage[NST];
+    const int buf_items = a.lt_max;
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) stage[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) lds[i] = stage[k];
+    }
+    __syncthreads();
+
+    int chain = 0;
     for (int cg = 0; cg < a.CGin; ++cg) {
-        __syncthreads();  // everyone is done reading the previous tile
-        for (int i = tid; i < Lt; i += 256) lds[i] = src[i];
-        __syncthreads();
+        // branch-free: the last group re-fetches its own tile instead of testing `cg + 1 < CGin`
+        src += (cg + 1 < a.CGin) ? a.in_cg_stride : 0;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 256;
+            if (i < Lt) stage[k] = src[i];
+        }
+        const char *tile = lds_b + (cg & 1) * buf_items * 8;
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             int2 w[8];
@@ -227,23 +226,34 @@ __global__ __launch_bounds__(256) void k_conv_i16(const int2 *__restrict__ in, i
             for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                const int2 x = *reinterpret_cast<const int2 *>(lds_b + rowaddr[p][tap / KS] + (tap % KS) * 8);
-                if (MODE == 0) {
-                    int t[8];
-                    dot8_shift(t, x, w, r, s);
+                int2 x = *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8);
+                // Form A's dot products do not depend on the accumulators, so hipcc would compute
+                // all 72x8 of a group up front (hundreds of live registers, SGPR spills).  An empty
+                // asm ties this pixel's x to the previous pixel's last accumulator: same order as
+                // form B gets naturally from accumulating into acc.  No instruction is emitted.
+                if (MODE == 0) asm volatile("" : "+v"(x.x) : "v"(chain));
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) acc[p][m] = (acc_t)clamp16((int)acc[p][m] + t[m]);
-                } else {
-#pragma unroll
-                    for (int m = 0; m < 8; ++m) {
-                        if (MODE == 2) acc[p][m] = (acc_t)step64((long)acc[p][m], x, w[m], a);
-                        else acc[p][m] = (acc_t)stepB((int)acc[p][m], x, w[m], nmask, r_vgpr, lo_b, hi_b);
-                    }
+                for (int m = 0; m < 8; ++m) {
+                    if (MODE == 2) acc[p][m] = (acc_t)step64((long)acc[p][m], x, w[m], a);
+                    else if (MODE == 1) acc[p][m] = (acc_t)stepB((int)acc[p][m], x, w[m], nmask, r_vgpr, lo_b, hi_b);
+                    else acc[p][m] = (acc_t)stepA((int)acc[p][m], x, w[m], r_vgpr, s);
                 }
+                if (MODE == 0) chain = (int)acc[p][7];
+            }
+            // form A: without a fence between taps hipcc hoists the scalar weight loads of all
+            // nine taps (144 SGPRs) to the top of the group and spills them
+            if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        {
+            int2 *nxt = lds + ((cg + 1) & 1) * buf_items;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int i = tid + k * 256;
+                if (i < Lt) nxt[i] = stage[k];
             }
         }
-        src += a.in_cg_stride;
         wq += KK * 32;
+        __syncthreads();
     }
 
     // write-back with integer leaky (core_compute.cpp:175-264): 2 items (8 channels) per pixel

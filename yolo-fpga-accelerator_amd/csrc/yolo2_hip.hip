@@ -128,6 +128,8 @@ static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
     return path;
 }
 
+constexpr int kMaxTileItems = 2048;  // 8 staging registers x 256 threads (k_conv_i16 NST <= 8)
+
 struct ConvPlan {
     int C = 0, N = 0, K = 0, H = 0, W = 0, leaky = 0;
     int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
@@ -141,12 +143,13 @@ struct ConvPlan {
 static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long out_base, int CGout)
 {
     const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
-    p.P = p.path == 2 ? 4 : 8;
+    p.P = p.path == 1 ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
     // small problems (single frame): fewer pixels per lane -> more workgroups
     const int npix = gin.B * gin.H * gin.W;
     while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * ((p.N + 31) / 32) < 1024) p.P >>= 1;
-    const int T = 64 * p.P;
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
+    while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
+    const int T = 64 * p.P;
     ConvArgs &a = p.args;
     a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
     a.CGin = gin.CG;
@@ -161,8 +164,17 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
-    p.lds_bytes = a.lt_max * 8;
+    p.lds_bytes = a.lt_max * 8 * 2;  // double-buffered input tile
     p.grid = dim3((npix + T - 1) / T, (p.N + 31) / 32, 1);
+}
+
+template <int KS, int MODE, int P>
+static void launch_conv_n(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
+{
+    const int nst = (p.args.lt_max + 255) / 256;
+    if (nst <= 2) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+    else if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 4>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+    else hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
 }
 
 template <int KS, int MODE>
@@ -170,10 +182,10 @@ static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const in
                           hipStream_t st)
 {
     switch (p.P) {
-    case 8: hipLaunchKernelGGL((k_conv_i16<KS, 8, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
-    case 4: hipLaunchKernelGGL((k_conv_i16<KS, 4, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
-    case 2: hipLaunchKernelGGL((k_conv_i16<KS, 2, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
-    default: hipLaunchKernelGGL((k_conv_i16<KS, 1, MODE>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args); break;
+    case 8: launch_conv_n<KS, MODE, 8>(p, in, out, wpk, bias, st); break;
+    case 4: launch_conv_n<KS, MODE, 4>(p, in, out, wpk, bias, st); break;
+    case 2: launch_conv_n<KS, MODE, 2>(p, in, out, wpk, bias, st); break;
+    default: launch_conv_n<KS, MODE, 1>(p, in, out, wpk, bias, st); break;
     }
 }
 
@@ -420,7 +432,11 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
     const short *beta = (const short *)(uintptr_t)beta_addr;
     const int so = qa_in + qw - qa_out, sb = qb - qa_out;
 
-    const bool tiled = kstride == 1 && ((ksize == 3 && padding == 1) || (ksize == 1 && padding == 0));
+    bool tiled = kstride == 1 && ((ksize == 3 && padding == 1) || (ksize == 1 && padding == 0));
+    if (tiled) {  // very wide images: the halo of a 64-pixel tile must fit the LDS staging scheme
+        const ActGeom g = make_geom(ifm_num, input_h, input_w, 1);
+        if (tile_items_bound(g, 64, ksize == 3 ? g.Wp + 1 : 0) > kMaxTileItems) tiled = false;
+    }
     if (!tiled) {
         const int n = ofm_num * output_h * output_w;
         hipLaunchKernelGGL(k_conv_ref_i16, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, w, beta, ifm_num, ofm_num,
