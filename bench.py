@@ -31,9 +31,13 @@ from yolo2_amd import dist as ydist  # noqa: E402
 from yolo2_amd import hipdrv, net, synth  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-# integer VALU peak: 256 CU x 4 SIMD x 32 lanes/clk x 2.4 GHz (same issue rate as the 157.3 TFLOP/s fp32 vector peak / 2)
-VALU_PEAK_TLANEOPS = 256 * 4 * 32 * 2.4e9 / 1e12
-OPS_PER_STEP = {0: 5, 1: 4, 2: None}   # VALU instructions per requant step of each kernel form
+# VALU issue roofline: 256 CU x 4 SIMD issue one wave64 instruction per 2 or 4 cycles depending on
+# the opcode (measured: profiles/r01_ubench_valu_issue_cost.txt).  SIMD issue cycles needed by one
+# requant step (4 channels x tap x output, per wave of 64 outputs):
+#   form A (MODE 0): v_mov 2 + 2 x v_dot2c 4 + v_ashrrev 4 + v_add 2 + v_med3 4 = 20
+#   form B (MODE 1): 2 x v_dot2c 4 + v_and_or 4 + v_med3 4                       = 16
+VALU_PEAK_TCYCLES = 256 * 4 * 2.4e9 / 1e12          # SIMD issue cycles per second at the 2.4 GHz max clock
+CYCLES_PER_STEP = {0: 20, 1: 16, 2: None}
 
 
 def conv_layer_bytes(l, batch):
@@ -172,14 +176,15 @@ def main():
         ach = (g["bytes"] / g["launches"]) / (avg_ms * 1e-3) / 1e9
         kname = f"k_conv_i16<KS={key[0]},P={key[1]},MODE={key[2]}>"
         conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
-        ops = OPS_PER_STEP.get(key[2])
+        cyc = CYCLES_PER_STEP.get(key[2])
         valu = None
-        if ops:
-            lane_ops = g["steps"] * ops / (g["ms"] * 1e-3) / 1e12
-            valu = {"bound": "valu_int", "kernel": kname, "achieved": lane_ops, "peak": VALU_PEAK_TLANEOPS,
-                    "unit": "T lane-ops/s", "frac": lane_ops / VALU_PEAK_TLANEOPS,
-                    "note": f"{ops} VALU instructions per (4 channels x tap x output) requant step; "
-                            "the int16 path is integer-VALU bound, not HBM bound (SURVEY.md 8d)"}
+        if cyc:
+            used = g["steps"] / 64 * cyc / (g["ms"] * 1e-3) / 1e12
+            valu = {"bound": "valu_issue", "kernel": kname, "achieved": used, "peak": VALU_PEAK_TCYCLES,
+                    "unit": "T SIMD issue cycles/s", "frac": used / VALU_PEAK_TCYCLES,
+                    "note": f"{cyc} SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs) at the "
+                            "measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz.  The int16 path is "
+                            "integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
         result = {
             "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -140,13 +140,18 @@ struct ConvPlan {
     ConvArgs args;
 };
 
-static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long out_base, int CGout)
+static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long out_base, int CGout, int forceP = 0)
 {
     const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
-    p.P = p.path == 1 ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
-    // small problems (single frame): fewer pixels per lane -> more workgroups
     const int npix = gin.B * gin.H * gin.W;
-    while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * ((p.N + 31) / 32) < 1024) p.P >>= 1;
+    const int maxP = p.path == 1 ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
+    if (forceP) {
+        p.P = std::min(forceP, maxP);
+    } else {
+        p.P = maxP;
+        // small problems (single frame): fewer pixels per lane -> more workgroups
+        while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * ((p.N + 31) / 32) < 1024) p.P >>= 1;
+    }
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
     const int T = 64 * p.P;
@@ -736,6 +741,49 @@ static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
     return YOLO2_SUCCESS;
 }
 
+// Pixels-per-lane (P) decides tile count, occupancy and how evenly a layer's workgroups divide
+// over the 256 CUs; the best value depends on layer shape and batch.  Time each candidate once
+// per layer on the layer's own buffers (integer kernels: timing does not depend on the data) and
+// keep the fastest.  ~0.2 s at batch 64; disable with YOLO2_AUTOTUNE=0.
+static int autotune(yolo2_hip_ctx *c)
+{
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), YOLO2_ERROR);
+    HIP_TRY(hipEventCreate(&e1), YOLO2_ERROR);
+    int ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+        const Tensor &tout = c->t_out[i];
+        const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
+        const int CGout = (kNet[i].n + 3) / 4;
+        float best = 1e30f;
+        int bestP = c->plan[i].P;
+        for (int P : {8, 4, 2, 1}) {
+            ConvPlan cand = c->plan[i];
+            plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
+            if (cand.P != P) continue;  // not available for this path / shape
+            float tmin = 1e30f;
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipEventRecord(e0, nullptr);
+                launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr);
+                (void)hipEventRecord(e1, nullptr);
+                HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
+                tmin = std::min(tmin, t);
+            }
+            if (tmin < best) { best = tmin; bestP = P; }
+        }
+        plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout, bestP);
+        ord++;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
 extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
 {
     if (!c) return fail(YOLO2_ERROR, "null ctx");
@@ -767,6 +815,8 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
         const int CGout = (kNet[i].n + 3) / 4;
         plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
     }
+    const char *at = getenv("YOLO2_AUTOTUNE");
+    if (!(at && at[0] == '0')) return autotune(c);
     return YOLO2_SUCCESS;
 }
 
