@@ -169,6 +169,13 @@ int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x
 
 /* ------------------------------------------------------------------- tier 3: helpers */
 
+/* The layer table the batched entry implements (config/yolov2.cfg as parsed by
+ * src/core/yolo_net.cpp:218-291).  desc = {type, c, h, w, n, size, stride, pad, leaky} with
+ * type 0 conv, 1 maxpool, 2 reorg, 3 route, 4 region (linux_app/include/yolo2_config.h:118-122).
+ * Hosts that parse a .cfg compare it with this before using yolo2_hip_run_batch_*. */
+int yolo2_hip_num_layers(void);
+int yolo2_hip_layer_desc(int layer_idx, int desc[9]);
+
 /* weights_reorg_int16.bin / bias_int16.bin carry one pad element after every odd-length
  * layer (yolo2_model.cpp:198-224).  Returns elements written, or -1 if the file is short. */
 long yolo2_strip_int16_layer_pad(const int16_t *file, size_t file_elems, const int *layer_len,

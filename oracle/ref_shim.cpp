@@ -64,4 +64,63 @@ int ref_yolov2_hls_ps(const char *cfg_path, const float *input, float *region_pr
     }
 }
 
+// ---- host logic of the reference (src/core/*.cpp), for parity tests of our own C++ host
+
+// letterbox_image (src/core/yolo_image.cpp:148-165) on a CHW float image
+void ref_letterbox(const float *chw, int w, int h, int c, int nw, int nh, float *out)
+{
+    image im = make_image(w, h, c);
+    std::memcpy(im.data, chw, sizeof(float) * (size_t)w * h * c);
+    image boxed = letterbox_image(im, nw, nh);
+    std::memcpy(out, boxed.data, sizeof(float) * (size_t)nw * nh * c);
+    free_image(im);
+    free_image(boxed);
+}
+
+// forward_region_layer + get_network_boxes + do_nms_sort (src/core/yolo_region.cpp:123-236,
+// src/core/yolo_post.cpp:54-85).  rows: all w*h*n detections as [x,y,w,h,objectness,prob[classes]].
+int ref_detect(const char *cfg_path, const float *region_raw, int im_w, int im_h, float thresh, float nms,
+               float *proc_out, float *rows, int max_rows)
+{
+    try {
+        network *net = load_network(const_cast<char *>(cfg_path));
+        if (!net) return -1;
+        set_batch_network(net, 1);
+        layer l = net->layers[net->n - 1];
+        forward_region_layer(l, const_cast<float *>(region_raw));
+        std::memcpy(proc_out, l.output, sizeof(float) * l.outputs);
+        int nboxes = 0;
+        detection *dets = get_network_boxes(net, im_w, im_h, thresh, 0.5f, 0, 1, &nboxes);
+        if (nms > 0) do_nms_sort(dets, nboxes, l.classes, nms);
+        const int n = nboxes < max_rows ? nboxes : max_rows;
+        for (int i = 0; i < n; ++i) {
+            float *r = rows + (size_t)i * (5 + l.classes);
+            r[0] = dets[i].bbox.x; r[1] = dets[i].bbox.y; r[2] = dets[i].bbox.w; r[3] = dets[i].bbox.h;
+            r[4] = dets[i].objectness;
+            for (int j = 0; j < l.classes; ++j) r[5 + j] = dets[i].prob[j];
+        }
+        free_detections(dets, nboxes);
+        return nboxes;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "ref_detect: %s\n", e.what());
+        return -2;
+    }
+}
+
+// the layer table the reference's own parser builds from a .cfg (src/core/yolo_net.cpp:218-291)
+// desc[i*12 + {type,c,h,w,out_c,out_h,out_w,n,size,stride,pad,leaky}] with our type codes
+int ref_parse_cfg(const char *cfg_path, int *net_whc, int *desc, int max_layers)
+{
+    network *net = load_network(const_cast<char *>(cfg_path));
+    if (!net) return -1;
+    net_whc[0] = net->w; net_whc[1] = net->h; net_whc[2] = net->c;
+    for (int i = 0; i < net->n && i < max_layers; ++i) {
+        layer l = net->layers[i];
+        int t = l.type == CONVOLUTIONAL ? 0 : l.type == MAXPOOL ? 1 : l.type == REORG ? 2 : l.type == ROUTE ? 3 : l.type == REGION ? 4 : -1;
+        int v[12] = {t, l.c, l.h, l.w, l.out_c, l.out_h, l.out_w, l.n, l.size, l.stride, l.pad, l.activation == LEAKY};
+        std::memcpy(desc + i * 12, v, sizeof(v));
+    }
+    return net->n;
+}
+
 }  // extern "C"

@@ -178,11 +178,54 @@ def gen_fullnet():
     print("wrote fullnet.npz")
 
 
+def gen_host():
+    """Host-logic fixtures from the reference's own src/core code: letterbox of a small synthetic
+    image, region activations + boxes + NMS of the int16 full-network region tensor, and the layer
+    table its parser builds from config/yolov2.cfg."""
+    out = {}
+    rng = np.random.default_rng(99)
+    rh = orclib.ref_host()
+    for (w, h, nw, nh) in [(57, 41, 96, 96), (33, 80, 96, 96), (200, 150, 64, 48), (96, 96, 96, 96)]:
+        img = rng.random((3, h, w), dtype=np.float32)
+        out[f"letterbox/{w}x{h}to{nw}x{nh}/in"] = (img * 255).round().astype(np.uint8)   # stored as bytes, /255 on use
+        img8 = out[f"letterbox/{w}x{h}to{nw}x{nh}/in"].astype(np.float32) / np.float32(255)
+        lb = np.zeros((3, nh, nw), dtype=np.float32)
+        rh.ref_letterbox(np.ascontiguousarray(img8), w, h, 3, nw, nh, lb)
+        out[f"letterbox/{w}x{h}to{nw}x{nh}/out"] = lb.copy()
+    full = np.load(os.path.join(HERE, "fullnet.npz"))
+    raw = full["i16/std/region_raw_i16"].astype(np.float32) * np.float32(2.0 ** -int(full["i16/std/final_q"]))
+    # give a few cells a strong objectness + class so that boxes survive realistic thresholds
+    raw = raw.reshape(5, 85, 13, 13).copy()
+    for (a, y, x, cls) in [(0, 3, 4, 16), (2, 6, 6, 1), (2, 6, 7, 1), (4, 10, 2, 7), (1, 6, 6, 1)]:
+        raw[a, 4, y, x] = 4.0
+        raw[a, 5 + cls, y, x] = 9.0
+    raw = raw.reshape(-1)
+    for (name, imw, imh, thresh, nms) in [("low", 768, 576, 0.05, 0.45), ("std", 768, 576, 0.25, 0.45), ("tall", 300, 500, 0.25, 0.3)]:
+        proc = np.zeros(425 * 169, dtype=np.float32)
+        rows = np.zeros((845, 85), dtype=np.float32)
+        n = rh.ref_detect(REF_CFG.encode(), np.ascontiguousarray(raw), imw, imh, thresh, nms, proc, rows, 845)
+        assert n == 845
+        out[f"detect/{name}/params"] = np.array([imw, imh, thresh, nms], dtype=np.float64)
+        out[f"detect/{name}/rows"] = orclib.canon_rows(rows)
+        out["detect/proc"] = proc
+        print("detect", name, "kept", len(out[f"detect/{name}/rows"]), "with class prob", int((out[f"detect/{name}/rows"][:, 5:] > 0).any(axis=1).sum()))
+    out["detect/raw"] = raw
+    whc = np.zeros(3, dtype=np.int32)
+    desc = np.zeros(40 * 12, dtype=np.int32)
+    n = rh.ref_parse_cfg(REF_CFG.encode(), whc, desc, 40)
+    out["cfg/net_whc"] = whc
+    out["cfg/desc"] = desc[: n * 12].reshape(n, 12)
+    np.savez_compressed(os.path.join(HERE, "host.npz"), **out)
+    print("wrote host.npz")
+
+
 if __name__ == "__main__":
     if not orclib.have_ref():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` in the build container")
-    what = sys.argv[1:] or ["kats", "fullnet"]
+    what = sys.argv[1:] or ["kats", "fullnet", "host"]
     if "kats" in what:
         gen_kats()
     if "fullnet" in what:
         gen_fullnet()
+    if "host" in what:
+        gen_host()

@@ -188,3 +188,37 @@ def ref_maxpool(x, C_, W, H):
                               C_, C_, 2, 2, W, H, OW, OH, 1, 0, 0, TM, 0, TR, TC,
                               (mLoops + 2) * TM, mLoops * TM, (mLoops + 1) * TM, 1, 0, 0, 0, 0)
     return out[:C_ * OH * w8(OW)].reshape(C_, OH, w8(OW))
+
+
+# ------------------------------------------------------------------ host logic (ours / reference)
+
+HOST_LIB = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "libyolo2_host.so")
+_host = None
+
+
+def host():
+    global _host
+    if _host is None:
+        lib = C.CDLL(HOST_LIB)
+        lib.y2h_last_error.restype = C.c_char_p
+        lib.y2h_letterbox.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        lib.y2h_region_forward.argtypes = [_f32p, _f32p]
+        lib.y2h_boxes_nms.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, C.c_int]
+        lib.y2h_parse_cfg.argtypes = [C.c_char_p, _i32p, _i32p, C.c_int, _f32p, _i32p]
+        lib.y2h_load_pnm.argtypes = [C.c_char_p, _i32p, _f32p, C.c_long]
+        _host = lib
+    return _host
+
+
+def ref_host():
+    lib = ref(True)
+    lib.ref_letterbox.argtypes = [_f32p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+    lib.ref_detect.argtypes = [C.c_char_p, _f32p, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, _f32p, C.c_int]
+    lib.ref_parse_cfg.argtypes = [C.c_char_p, _i32p, _i32p, C.c_int]
+    return lib
+
+
+def canon_rows(rows):
+    """Detections with objectness > 0, in a canonical order (the reference's qsort is unstable)."""
+    r = rows[rows[:, 4] > 0]
+    return r[np.lexsort((r[:, 3], r[:, 2], r[:, 1], r[:, 0]))]

@@ -1,0 +1,65 @@
+"""GPU test of the repo's own CLI: yolov2_detect --backend hip end to end (PPM in, weight files in
+the reference's on-disk formats, region dumps + boxes out), checked against the library driven
+from Python on the same letterboxed frame and against the reference-derived host fixtures."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orclib
+from yolo2_amd import hipdrv, synth
+
+pytestmark = pytest.mark.gpu
+PKG = os.path.join(orclib.ROOT, "yolo-fpga-accelerator_amd")
+CLI = os.path.join(PKG, "yolov2_detect")
+
+
+def test_cli_end_to_end(tmp_path):
+    assert os.path.exists(CLI), "build yolov2_detect first (make -C yolo-fpga-accelerator_amd)"
+    model = synth.SynthModel(seed=1, obj_bias=2.0)
+    model.write_files(str(tmp_path / "weights"), fp32=False)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (300, 500, 3), dtype=np.uint8)
+    ppm = tmp_path / "img.ppm"
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n500 300\n255\n" + img.tobytes())
+    env = dict(os.environ, YOLO2_DUMP_REGION_RAW=str(tmp_path / "raw.txt"), YOLO2_DUMP_REGION=str(tmp_path / "proc.txt"))
+    r = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names"),
+                        "--weights", str(tmp_path / "weights"), "--input", str(ppm), "--output", str(tmp_path / "out" / "pred"),
+                        "--thresh", "0.6", "--batch", "2", "--json", "--backend", "hip", "--precision", "int16"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Predicted in" in r.stdout and "inference time:" in r.stdout
+    assert os.path.exists(tmp_path / "out" / "pred.ppm")
+
+    # same frame through the library from Python
+    chw = img.transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+    boxed = np.zeros((3, 416, 416), dtype=np.float32)
+    orclib.host().y2h_letterbox(np.ascontiguousarray(chw), 500, 300, 3, 416, 416, boxed)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    region, q = ctx.run_batch_host(boxed[None])
+    ctx.close()
+    raw = np.loadtxt(tmp_path / "raw.txt")
+    assert np.array_equal(np.rint(raw * (1 << q)).astype(np.int64), region[0].reshape(-1).astype(np.int64))
+    # ... and against the oracle
+    orclib.oracle().orc_set_threads(16)
+    ri, rf, _ = orclib.forward_i16(model, boxed)
+    assert np.array_equal(ri, region[0].reshape(-1))
+    proc = np.zeros_like(rf)
+    orclib.oracle().orc_region_forward(rf, proc)
+    assert np.allclose(np.loadtxt(tmp_path / "proc.txt"), proc, rtol=0, atol=1e-7)
+    # boxes printed by the CLI == host library on the same tensor
+    rows = np.zeros((845, 85), dtype=np.float32)
+    kept = orclib.host().y2h_boxes_nms(np.ascontiguousarray(proc), 500, 300, 0.6, 0.45, rows, 845)
+    expect = int((rows[:kept, 5:] > 0.6).sum())
+    assert f"{expect} detection(s) above 0.60" in r.stdout
+    assert r.stdout.count('{"label"') == expect
+
+
+def test_cli_rejects_other_backends_and_missing_files(tmp_path):
+    r = subprocess.run([CLI, "--backend", "hls"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unsupported backend" in r.stderr
+    r = subprocess.run([CLI, "--cfg", "/nonexistent.cfg"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 1 and "Fatal error" in r.stderr

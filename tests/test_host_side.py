@@ -1,0 +1,97 @@
+"""CPU tests of the repo's own C++ host (yolo-fpga-accelerator_amd/host) against fixtures
+generated from the reference's src/core code (tests/golden/make_golden.py gen_host)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orclib
+from yolo2_amd import net
+
+HOSTG = np.load(os.path.join(orclib.ROOT, "tests", "golden", "host.npz"))
+PKG = os.path.join(orclib.ROOT, "yolo-fpga-accelerator_amd")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def built():
+    subprocess.run(["make", "-s", "-C", PKG, os.path.join(PKG, "libyolo2_host.so")], check=True)
+
+
+def test_cfg_parser_matches_reference_parser_table():
+    """Our parser on our generated cfg == the reference's parser on its config/yolov2.cfg."""
+    whc = np.zeros(3, dtype=np.int32)
+    desc = np.zeros(40 * 12, dtype=np.int32)
+    anchors = np.zeros(10, dtype=np.float32)
+    rp = np.zeros(4, dtype=np.int32)
+    n = orclib.host().y2h_parse_cfg(os.path.join(PKG, "config", "yolov2.cfg").encode(), whc, desc, 40, anchors, rp)
+    assert n == 32, orclib.host().y2h_last_error()
+    want = HOSTG["cfg/desc"]
+    got = desc[: n * 12].reshape(n, 12)
+    assert list(whc) == list(HOSTG["cfg/net_whc"]) == [416, 416, 3]
+    for i in range(32):
+        t = want[i, 0]
+        cols = list(range(12)) if t == 0 else ([0, 1, 2, 3, 4, 5, 6, 8, 9] if t == 1 else [0, 1, 2, 3, 4, 5, 6] if t in (2, 4) else [0, 4, 5, 6])
+        assert list(got[i, cols]) == list(want[i, cols]), (i, got[i], want[i])
+    assert np.allclose(anchors, net.ANCHORS) and list(rp) == [80, 4, 5, 1]
+    # and the python layer table agrees with both
+    for l in net.LAYERS:
+        if l.type == net.CONV:
+            assert list(got[l.idx, [1, 2, 3, 7, 8, 9, 10, 11]]) == [l.c, l.h, l.w, l.n, l.size, l.stride, l.pad, int(l.leaky)]
+
+
+def test_cfg_errors():
+    whc = np.zeros(3, dtype=np.int32); desc = np.zeros(12, dtype=np.int32)
+    a = np.zeros(10, dtype=np.float32); rp = np.zeros(4, dtype=np.int32)
+    assert orclib.host().y2h_parse_cfg(b"/nonexistent.cfg", whc, desc, 1, a, rp) == -1
+    assert b"Couldn't open file" in orclib.host().y2h_last_error()
+
+
+@pytest.mark.parametrize("key", sorted({k.split("/")[1] for k in HOSTG.files if k.startswith("letterbox/")}))
+def test_letterbox_bit_exact(key):
+    src, dst = key.split("to")
+    w, h = (int(v) for v in src.split("x"))
+    nw, nh = (int(v) for v in dst.split("x"))
+    img = HOSTG[f"letterbox/{key}/in"].astype(np.float32) / np.float32(255)
+    out = np.zeros((3, nh, nw), dtype=np.float32)
+    orclib.host().y2h_letterbox(np.ascontiguousarray(img), w, h, 3, nw, nh, out)
+    want = HOSTG[f"letterbox/{key}/out"]
+    assert np.array_equal(out.view(np.uint32), want.view(np.uint32))
+
+
+def test_region_forward_bit_exact():
+    raw = np.ascontiguousarray(HOSTG["detect/raw"])
+    proc = np.zeros_like(raw)
+    orclib.host().y2h_region_forward(raw, proc)
+    assert np.array_equal(proc, HOSTG["detect/proc"])
+    p = proc.reshape(5, 85, 169)
+    assert np.allclose(p[:, 5:, :].sum(axis=1), 1.0, atol=1e-5)      # softmax over classes
+    assert np.all((p[:, [0, 1, 4], :] > 0) & (p[:, [0, 1, 4], :] < 1))   # logistic
+
+
+@pytest.mark.parametrize("name", ["low", "std", "tall"])
+def test_boxes_and_nms_match_reference(name):
+    imw, imh, thresh, nms = HOSTG[f"detect/{name}/params"]
+    rows = np.zeros((845, 85), dtype=np.float32)
+    kept = orclib.host().y2h_boxes_nms(np.ascontiguousarray(HOSTG["detect/proc"]), int(imw), int(imh), float(thresh),
+                                       float(nms), rows, 845)
+    got = orclib.canon_rows(rows[:kept])
+    want = HOSTG[f"detect/{name}/rows"]
+    assert got.shape == want.shape
+    assert np.array_equal(got[:, :5], want[:, :5])          # boxes + objectness: bit-exact
+    assert np.array_equal(got[:, 5:] > 0, want[:, 5:] > 0)  # which class probabilities survive NMS
+    assert np.array_equal(got[:, 5:], want[:, 5:])
+
+
+def test_pnm_loader(tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (7, 5, 3), dtype=np.uint8)
+    p = tmp_path / "t.ppm"
+    with open(p, "wb") as f:
+        f.write(b"P6\n# comment\n5 7\n255\n" + img.tobytes())
+    whc = np.zeros(3, dtype=np.int32)
+    out = np.zeros(3 * 7 * 5, dtype=np.float32)
+    assert orclib.host().y2h_load_pnm(str(p).encode(), whc, out, out.size) == 0
+    assert list(whc) == [5, 7, 3]
+    assert np.array_equal(out.reshape(3, 7, 5), img.transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+    assert orclib.host().y2h_load_pnm(b"/nonexistent.ppm", whc, out, out.size) == -1

@@ -87,6 +87,19 @@ static const LayerDesc kNet[32] = {
     {L_CONV, 1024, 13, 13, 425, 1, 0},  {L_REGION, 425, 13, 13, 0, 0, 0},
 };
 
+extern "C" int yolo2_hip_num_layers(void) { return 32; }
+extern "C" int yolo2_hip_layer_desc(int i, int desc[9])
+{
+    if (i < 0 || i >= 32 || !desc) return YOLO2_ERROR;
+    const LayerDesc &l = kNet[i];
+    static const int type_code[] = {0, 1, 3, 2, 4};  // yolo2_config.h:118-122 numbering
+    const int stride = l.type == L_MAX || l.type == L_REORG ? 2 : (l.type == L_CONV ? 1 : 0);
+    const int pad = l.type == L_CONV && l.size == 3 ? 1 : 0;
+    const int v[9] = {type_code[l.type], l.c, l.h, l.w, l.n, l.size, stride, pad, l.leaky};
+    for (int k = 0; k < 9; ++k) desc[k] = v[k];
+    return YOLO2_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------- launch helpers
 
 struct ShiftSpec {

@@ -28,6 +28,7 @@ EXPORTS = [
     "yolo2_hip_layer_path", "yolo2_hip_set_batch", "yolo2_hip_run_batch_int16", "yolo2_hip_run_batch_int16_host",
     "yolo2_hip_debug_layer_output", "yolo2_hip_set_profiling", "yolo2_hip_layer_times_ms",
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
+    "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
 ]
 
 

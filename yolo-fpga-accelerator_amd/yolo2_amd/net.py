@@ -91,6 +91,27 @@ REGION_ELEMS = 425 * 13 * 13
 ANCHORS = [0.57273, 0.677385, 1.87446, 2.06253, 3.33843, 5.47434, 7.88282, 3.52778, 9.77052, 9.16828]
 
 
+def to_cfg() -> str:
+    """A Darknet .cfg for this network with only the keys the parsers read (our
+    host/y2_host.cpp and the reference's src/core/yolo_layers.cpp:90-117,312-326)."""
+    out = ["[net]", "batch=1", "width=416", "height=416", "channels=3", ""]
+    for l in LAYERS:
+        if l.type == CONV:
+            out += ["[convolutional]"] + (["batch_normalize=1"] if l.leaky else []) + \
+                   [f"filters={l.n}", f"size={l.size}", "stride=1", "pad=1",
+                    "activation=" + ("leaky" if l.leaky else "linear"), ""]
+        elif l.type == MAXPOOL:
+            out += ["[maxpool]", "size=2", "stride=2", ""]
+        elif l.type == ROUTE:
+            out += ["[route]", "layers=" + ("-9" if l.idx == 25 else "-1,-4"), ""]
+        elif l.type == REORG:
+            out += ["[reorg]", "stride=2", ""]
+        elif l.type == REGION:
+            out += ["[region]", "anchors = " + ", ".join(repr(a) for a in ANCHORS), "classes=80", "coords=4",
+                    "num=5", "softmax=1", ""]
+    return "\n".join(out)
+
+
 def w8(w: int) -> int:
     return (w + 7) // 8 * 8
 
