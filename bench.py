@@ -93,6 +93,78 @@ def cpu_baseline(model, frame, gpu_region):
     return out
 
 
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
+
+
+def bench_fp16(args, world, rank, local_rank, dev):
+    """configs[3]: YOLOv2 fp16 MFMA path.  Same protocol as the int16 bench; weights are uploaded
+    by every rank itself from the seeded generator (203 MB fp32 -> fp16 on the device)."""
+    B = args.batch
+    model = synth.SynthModel(seed=1)
+    ctx = hipdrv.Yolo2Hip(local_rank)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    lo, hi = ydist.shard_range(B * world, rank, world)
+    frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
+    region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        ctx.run_batch_fp16_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_profiling(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    layer_ms = ctx.layer_times_ms()
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
+        flops = 2.0 * net.macs_per_frame() * B
+        ach = flops / (conv_ms * 1e-3) / 1e12
+        result = {
+            "metric": "YOLOv2 fp16 416x416 frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"YOLOv2 fp16 416x416 batch={B} per GPU, MFMA implicit-GEMM conv (fp32 accumulate)",
+                       "batch_per_gpu": B, "global_batch": B * world},
+            "roofline": {"bound": "mfma", "kernel": "k_conv_f16", "launches_per_step": len(net.CONVS),
+                         "avg_launch_ms": conv_ms / len(net.CONVS), "achieved": ach, "peak": MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_launch": flops / len(net.CONVS)},
+            "layer_ms": [round(float(x), 4) for x in layer_ms], "conv_ms_per_step": conv_ms,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import orclib
+            orclib.oracle().orc_set_threads(1)
+            t0 = time.perf_counter()
+            ref = orclib.forward_f32(model, frames[0].cpu().numpy())
+            cdt = time.perf_counter() - t0
+            err = float(np.abs(region[0].cpu().numpy().reshape(-1) - ref).max())
+            result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
+                                      "sample": "1 frame through oracle/yolo2_oracle.c fp32 (bit-exact restatement of the reference's fp32 path), single thread",
+                                      "seconds_per_frame": cdt, "gpu_max_abs_err_vs_cpu": err}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +172,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (configs[2]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["int16", "fp16"], default="int16",
+                    help="int16 = the headline bit-exact path; fp16 = MFMA implicit-GEMM path (configs[3], use --batch 256)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,6 +192,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
+    if args.precision == "fp16":
+        return bench_fp16(args, world, rank, local_rank, dev)
     # ---- init: rank 0 builds the synthetic weight set; ONE broadcast puts it on every GPU
     model = synth.SynthModel(seed=1) if rank == 0 else None
     w, b, wq, bq, aq = ydist.broadcast_model(model, dev)

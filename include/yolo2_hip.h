@@ -150,6 +150,18 @@ int yolo2_hip_run_batch_int16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch
 int yolo2_hip_run_batch_int16_host(yolo2_hip_ctx *ctx, const float *frames, int batch,
                                    int16_t *region, int *final_q);
 
+/* ---- fp16 MFMA path (floating-point form of the same network: a true dense contraction).
+ * Weights as yolov2_hls_ps holds them for Precision::FP32 (weights_reorg.bin / bias.bin,
+ * yolo2_model.cpp:171-181); converted once to fp16 in a K-contiguous layout on the device.
+ * Activations fp16, accumulation fp32 on v_mfma_f32_32x32x16_f16, bias + leaky in fp32.
+ * region_dev: float [batch][425][13][13] (what yolov2_hls_ps hands to forward_region_layer in
+ * fp32 mode, yolo2_model.cpp:422-424).  Validated against the fp32 reference at box tolerance. */
+int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *ctx, const float *weights_reorg, size_t n_weights,
+                                const float *bias, size_t n_bias);
+int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch, uint64_t region_dev,
+                             void *stream);
+int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *ctx, const float *frames, int batch, float *region);
+
 /* Copies layer `layer_idx`'s output of frame `frame` from the last run into the reference's
  * [C][H][W8] int16 layout (pad columns zero) -- the yolov2_region_*_hw.txt style parity hook
  * (SURVEY.md section 4).  out_elems receives C*H*W8. */

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/yolo2_hip.h"
+#include "kernels_f16.hpp"
 #include "kernels_int16.hpp"
 #include "layout.hpp"
 
@@ -556,6 +557,18 @@ struct yolo2_hip_ctx {
     int reorg_shift = 0, final_q = 0;
     int batch = 0;
     Tensor t_in, t_out[32], t_cat;
+    // ---- fp16 MFMA path
+    struct HalfTensor {
+        int C = 0, Cp = 0, H = 0, W = 0, Wp = 0, PL = 0, B = 0;
+        size_t items = 0;
+        _Float16 *d = nullptr;
+    };
+    bool f16_loaded = false;
+    _Float16 *wh = nullptr;
+    float *biasf = nullptr;
+    long wh_off[YOLO2_N_CONV], biasf_off[YOLO2_N_CONV];
+    int f16_batch = 0;
+    HalfTensor h_in, h_out[32], h_cat;
     // per-layer device timing: a ring of event sets, one per profiled run (hipEvents on the
     // stream the kernels are launched on); the analogue of yolo2_inference.c:75-142
     static constexpr int kProfSlots = 32;
@@ -591,12 +604,27 @@ static void free_activations(yolo2_hip_ctx *c)
     c->batch = 0;
 }
 
+static void free_f16_activations(yolo2_hip_ctx *c)
+{
+    if (c->h_in.d) (void)hipFree(c->h_in.d);
+    if (c->h_cat.d) (void)hipFree(c->h_cat.d);
+    c->h_in.d = c->h_cat.d = nullptr;
+    for (int i = 0; i < 32; ++i) {
+        if (c->h_out[i].d && i != 24 && i != 27) (void)hipFree(c->h_out[i].d);
+        c->h_out[i].d = nullptr;
+    }
+    c->f16_batch = 0;
+}
+
 extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     free_activations(c);
+    free_f16_activations(c);
+    if (c->wh) (void)hipFree(c->wh);
+    if (c->biasf) (void)hipFree(c->biasf);
     if (c->wpk) (void)hipFree(c->wpk);
     if (c->bias_pk) (void)hipFree(c->bias_pk);
     if (c->ev_made)
@@ -996,4 +1024,177 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
     (void)hipFree(tmp);
     if (e != hipSuccess) return fail(YOLO2_DMA_ERROR, "D2H failed: %s", hipGetErrorString(e));
     return YOLO2_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------- fp16 MFMA path
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weights_reorg, size_t n_weights,
+                                           const float *bias, size_t n_bias)
+{
+    if (!c || !weights_reorg || !bias) return fail(YOLO2_ERROR, "null argument");
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    long wtot = 0, btot = 0;
+    int ord = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            const LayerDesc &l = kNet[i];
+            const int npad = round_up(l.n, kBN);
+            c->wh_off[ord] = wtot;
+            c->biasf_off[ord] = btot;
+            wtot += i == 0 ? (long)npad * 32 : (long)npad * l.size * l.size * round_up(l.c, 32);
+            btot += npad;
+            ord++;
+        }
+    if (c->wh) (void)hipFree(c->wh);
+    if (c->biasf) (void)hipFree(c->biasf);
+    c->wh = nullptr;
+    c->biasf = nullptr;
+    float *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->wh, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&c->biasf, (size_t)btot * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    long woff = 0, boff = 0;
+    ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type != L_CONV) continue;
+        const int npad = round_up(l.n, kBN), KK = l.size * l.size;
+        const int Cp = i == 0 ? 32 : round_up(l.c, 32);
+        const long n = (long)npad * (i == 0 ? 1 : KK) * Cp;
+        hipLaunchKernelGGL(k_pack_weights_f16, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
+                           c->wh + c->wh_off[ord], c->biasf + c->biasf_off[ord], bd + boff, l.c, l.n, KK, Cp, npad, i == 0 ? 1 : 0);
+        woff += yolo2_weight_len[ord];
+        boff += yolo2_bias_len[ord];
+        ord++;
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+    (void)hipFree(wd);
+    (void)hipFree(bd);
+    c->f16_loaded = true;
+    return YOLO2_SUCCESS;
+}
+
+static int alloc_half(yolo2_hip_ctx::HalfTensor &t, int C, int Cp, int H, int W, int B)
+{
+    t.C = C; t.Cp = Cp; t.H = H; t.W = W; t.Wp = W + 1; t.PL = (H + 1) * t.Wp; t.B = B;
+    t.items = (size_t)kLead + (size_t)B * t.PL + kTail;
+    HIP_TRY(hipMalloc((void **)&t.d, t.items * Cp * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(t.d, 0, t.items * Cp * 2), YOLO2_DMA_ERROR);  // zeros = conv padding and channel padding
+    return YOLO2_SUCCESS;
+}
+
+static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
+{
+    if (c->f16_batch == B) return YOLO2_SUCCESS;
+    free_f16_activations(c);
+    int rc;
+    if ((rc = alloc_half(c->h_in, 27, 32, 416, 416, B))) return rc;      // layer-0 im2col items
+    if ((rc = alloc_half(c->h_cat, 1280, 1280, 13, 13, B))) return rc;
+    for (int i = 0; i < 30; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type == L_CONV && i != 24) {
+            if ((rc = alloc_half(c->h_out[i], l.n, round_up(l.n, 32), l.h, l.w, B))) return rc;
+        } else if (l.type == L_MAX) {
+            if ((rc = alloc_half(c->h_out[i], l.c, round_up(l.c, 32), l.h / 2, l.w / 2, B))) return rc;
+        }
+    }
+    c->h_out[24] = c->h_cat;
+    c->h_out[27] = c->h_cat;
+    c->f16_batch = B;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, int batch, uint64_t region_dev, void *stream)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!c->f16_loaded) return fail(YOLO2_ERROR, "fp32 weights not loaded (yolo2_hip_load_weights_fp32)");
+    if (!frames_dev || !region_dev) return fail(YOLO2_ERROR, "null buffer address");
+    if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    int rc = ensure_f16_batch(c, batch);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = batch;
+    hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    {
+        const auto &g = c->h_in;
+        hipLaunchKernelGGL(k_pack_input_f16, dim3(blocks_for((long)B * g.H * g.W, 256)), dim3(256), 0, st,
+                           (const float *)(uintptr_t)frames_dev, g.d, B, g.H, g.W, g.Wp, g.PL);
+    }
+    int ord = 0;
+    const yolo2_hip_ctx::HalfTensor *cur = &c->h_in;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        switch (l.type) {
+        case L_CONV: {
+            const auto *tin = i == 26 ? &c->h_out[16] : (i == 29 ? &c->h_cat : cur);
+            const auto &tout = c->h_out[i];
+            ConvF16Args a;
+            a.B = B; a.H = l.h; a.W = l.w; a.Wp = l.w + 1; a.PL = (l.h + 1) * (l.w + 1);
+            a.Cp_in = tin->Cp;
+            a.Cp_out = i == 30 ? 0 : tout.Cp;
+            a.N = l.n;
+            a.out_ch_off = i == 24 ? 256 : 0;
+            a.n_store = i == 30 ? l.n : round_up(l.n, 32);
+            a.npix = B * l.h * l.w;
+            a.leaky = l.leaky;
+            a.KS = i == 0 ? 1 : l.size;   // layer 0 runs as a 1x1 conv over im2col items
+            const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, kBN) / kBN);
+            hipLaunchKernelGGL(k_conv_f16, grid, dim3(256), 0, st, (const _Float16 *)tin->d, (const _Float16 *)(c->wh + c->wh_off[ord]),
+                               (const float *)(c->biasf + c->biasf_off[ord]), i == 30 ? (_Float16 *)nullptr : tout.d,
+                               i == 30 ? (float *)(uintptr_t)region_dev : (float *)nullptr, a);
+            if (i != 30) cur = &c->h_out[i];
+            ord++;
+            break;
+        }
+        case L_MAX: {
+            const auto &gi = *cur, &go = c->h_out[i];
+            const long n = (long)B * go.H * go.W * (go.Cp / 8);
+            hipLaunchKernelGGL(k_maxpool2_f16, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const _Float16 *)gi.d, go.d, go.Cp, B,
+                               go.H, go.W, gi.Wp, gi.PL, go.Wp, go.PL);
+            cur = &c->h_out[i];
+            break;
+        }
+        case L_REORG: {
+            const auto &gi = *cur, &go = c->h_cat;
+            hipLaunchKernelGGL(k_reorg_f16, dim3(blocks_for((long)B * 256 * 169, 256)), dim3(256), 0, st, (const _Float16 *)gi.d,
+                               go.d, B, gi.Cp, gi.Wp, gi.PL, go.Cp, go.Wp, go.PL);
+            cur = &c->h_cat;
+            break;
+        }
+        default:
+            break;  // route: concat by placement; region: the last conv already wrote the dense fp32 tensor
+        }
+        if (ev) (void)hipEventRecord(ev[i + 1], st);
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    if (ev) c->prof_runs++;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *c, const float *frames, int batch, float *region)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    float *fd = nullptr, *rd = nullptr;
+    HIP_TRY(hipMalloc((void **)&fd, (size_t)batch * YOLO2_FRAME_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&rd, (size_t)batch * YOLO2_REGION_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(fd, frames, (size_t)batch * YOLO2_FRAME_ELEMS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    int rc = yolo2_hip_run_batch_fp16(c, (uint64_t)(uintptr_t)fd, batch, (uint64_t)(uintptr_t)rd, nullptr);
+    if (rc == YOLO2_SUCCESS) {
+        hipError_t e = hipMemcpy(region, rd, (size_t)batch * YOLO2_REGION_ELEMS * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(YOLO2_DMA_ERROR, "D2H of region tensor failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(fd);
+    (void)hipFree(rd);
+    return rc;
 }

@@ -29,6 +29,7 @@ EXPORTS = [
     "yolo2_hip_debug_layer_output", "yolo2_hip_set_profiling", "yolo2_hip_layer_times_ms",
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
+    "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
 ]
 
 
@@ -80,6 +81,9 @@ def lib():
     L.yolo2_hip_conv_launch_info.argtypes = [vp, i32] + [C.POINTER(i32)] * 5
     L.yolo2_strip_int16_layer_pad.argtypes = [vp, C.c_size_t, vp, i32, vp]
     L.yolo2_strip_int16_layer_pad.restype = C.c_long
+    L.yolo2_hip_load_weights_fp32.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    L.yolo2_hip_run_batch_fp16.argtypes = [vp, u64, i32, u64, vp]
+    L.yolo2_hip_run_batch_fp16_host.argtypes = [vp, vp, i32, vp]
     L.memory_get_phys_addr.restype = u64
     L.memory_get_phys_addr.argtypes = [vp]
     _lib = L
@@ -241,6 +245,25 @@ class Yolo2Hip:
               "yolo2_hip_run_batch_int16_host")
         self.final_q = q.value
         return region, q.value
+
+    # ---- fp16 MFMA path
+    def load_weights_fp32(self, weights_f32, bias_f32):
+        w = np.ascontiguousarray(weights_f32, dtype=np.float32)
+        b = np.ascontiguousarray(bias_f32, dtype=np.float32)
+        check(lib().yolo2_hip_load_weights_fp32(self._h, w.ctypes.data_as(C.c_void_p), w.size,
+                                                b.ctypes.data_as(C.c_void_p), b.size), "yolo2_hip_load_weights_fp32")
+
+    def run_batch_fp16_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0):
+        check(lib().yolo2_hip_run_batch_fp16(self._h, frames_ptr, batch, region_ptr, C.c_void_p(stream)),
+              "yolo2_hip_run_batch_fp16")
+
+    def run_batch_fp16_host(self, frames: np.ndarray) -> np.ndarray:
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        B = frames.shape[0]
+        region = np.empty((B, 425, 13, 13), dtype=np.float32)
+        check(lib().yolo2_hip_run_batch_fp16_host(self._h, frames.ctypes.data_as(C.c_void_p), B,
+                                                  region.ctypes.data_as(C.c_void_p)), "yolo2_hip_run_batch_fp16_host")
+        return region
 
     def debug_layer_output(self, layer_idx: int, frame: int = 0) -> np.ndarray:
         l = net.LAYERS[layer_idx]
