@@ -36,8 +36,9 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # requant step (4 channels x tap x output, per wave of 64 outputs):
 #   form A (MODE 0): v_mov 2 + 2 x v_dot2c 4 + v_ashrrev 4 + v_add 2 + v_med3 4 = 20
 #   form B (MODE 1): 2 x v_dot2c 4 + v_and_or 4 + v_med3 4                       = 16
+#   form C (MODE 3): 2 x v_dot2 4 + v_ashrrev(_sdwa) 4 + half a v_pk_add_i16 2   = 14
 VALU_PEAK_TCYCLES = 256 * 4 * 2.4e9 / 1e12          # SIMD issue cycles per second at the 2.4 GHz max clock
-CYCLES_PER_STEP = {0: 20, 1: 16, 2: None}
+CYCLES_PER_STEP = {0: 20, 1: 16, 2: None, 3: 14}
 
 
 def conv_layer_bytes(l, batch):

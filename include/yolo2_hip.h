@@ -129,8 +129,10 @@ int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_
                                      int n_weight_q, const int32_t *bias_q, int n_bias_q,
                                      const int32_t *act_q, int n_act_q);
 
-/* 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 2 = 64-bit exact path,
- * <0 = bad ordinal / not loaded.  (csrc/kernels_int16.hpp explains the forms.) */
+/* 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 3 = form C (packed int16
+ * accumulators), 2 = 64-bit exact path, <0 = bad ordinal / not loaded.  All are bit-exact; the
+ * loader picks the narrowest one it can PROVE exact for the weights and Q values at hand
+ * (csrc/kernels_int16.hpp explains the forms). */
 int yolo2_hip_layer_path(yolo2_hip_ctx *ctx, int conv_ordinal);
 
 /* (Re)allocates the activation tensors for exactly `batch` frames per call. */

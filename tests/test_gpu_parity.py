@@ -46,11 +46,12 @@ def force_path(monkeypatch):
 
 # ------------------------------------------------------------------ per-layer driver calls
 
-@pytest.mark.parametrize("path", [None, 0, 2])
+@pytest.mark.parametrize("path", [None, 0, 1, 2, 3])
 @pytest.mark.parametrize("name", [str(n) for n in KAT["conv_i16/names"]])
 def test_conv_i16_kat_bit_exact(name, path, force_path):
     """Every known-answer conv case, through the tiled kernel's three arithmetic paths
-    (default = narrowest provably exact; 0 = 32-bit form A where legal; 2 = 64-bit)."""
+    (default = narrowest provably exact; 0/1/3 = forms A/B/C where the loader proves them legal,
+    otherwise its own choice; 2 = 64-bit)."""
     force_path(path)
     C, N, K, stride, W, H, pad, leaky, Qw, Qai, Qao, Qb = (int(v) for v in KAT[f"conv_i16/{name}/params"])
     x, wr, b, y = (KAT[f"conv_i16/{name}/{k}"] for k in ("x", "w_reorg", "bias", "y"))
@@ -102,7 +103,7 @@ def test_random_conv_vs_oracle(seed, force_path):
     wr = synth.reorg_weights(w, C, N, K)
     leaky = int(rng.integers(0, 2))
     want = orclib.conv_i16(x, wr, b, C, N, K, 1, W, H, pad, leaky, Qw, Qai, Qao, Qb)
-    for path in (None, 0):
+    for path in (None, 0, 1, 3):
         force_path(path)
         got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, 1, W, H, pad, leaky, Qw, Qai, Qao, Qb)
         assert np.array_equal(got, want), (seed, path)
@@ -200,14 +201,38 @@ def test_fullnet_paths_and_64bit_fallback(monkeypatch):
     model = synth.SynthModel(seed=1)
     frame = synth.frames(7, 1)
     want = FULL["i16/std/region_raw_i16"].reshape(425, 13, 13)
-    for force in ("2", "0"):
+    for force in ("2", "0", "1", "3"):
         monkeypatch.setenv("YOLO2_FORCE_PATH", force)
         ctx = hipdrv.Yolo2Hip(0)
         ctx.load_model(model)
-        assert set(ctx.layer_paths()) == {int(force)}
+        paths = ctx.layer_paths()
+        if force in ("2", "0"):
+            assert set(paths) == {int(force)}
+        else:   # forms B/C where provable for this layer's weights and Q, the default otherwise
+            assert paths.count(int(force)) >= 20, paths
         region, _ = ctx.run_batch_host(frame)
         assert np.array_equal(region[0], want), force
         ctx.close()
+
+
+@pytest.mark.parametrize("P", [1, 2, 4, 8])
+@pytest.mark.parametrize("path", ["0", "1", "3"])
+def test_fullnet_every_tile_shape_and_form(P, path, monkeypatch):
+    """Every (pixels-per-lane, arithmetic form) instantiation of the conv kernel on the whole
+    network, 3 frames (so tiles straddle frame boundaries), against the reference fixture."""
+    monkeypatch.setenv("YOLO2_FORCE_P", str(P))
+    monkeypatch.setenv("YOLO2_FORCE_PATH", path)
+    model = synth.SynthModel(seed=1)
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(8, 1), synth.frames(7, 1)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    ctx.set_batch(3)
+    assert all(ctx.conv_launch_info(o)["pixels_per_lane"] == min(P, 4 if path == "0" else 8) for o in range(23))
+    region, _ = ctx.run_batch_host(frames)
+    want = FULL["i16/std/region_raw_i16"].reshape(425, 13, 13)
+    assert np.array_equal(region[0], want) and np.array_equal(region[2], want)
+    assert not np.array_equal(region[1], want)
+    ctx.close()
 
 
 def test_extreme_weights_select_wide_path():

@@ -71,6 +71,38 @@ __device__ __forceinline__ int stepA(int acc, const int2 x, const int2 w, const 
     return clamp16(acc + (d >> s));
 }
 
+// Form C (3.5 instructions = 14 cycles per step, tightest bound): two int16 accumulators share a
+// VGPR and are updated by ONE saturating packed add, v_pk_add_i16 clamp == sat16(acc + t) for both
+// halves -- legal when every t = (p + round) >> s and the shifted bias fit int16, which the host
+// proves from the weights.  The shift of the second value writes the upper half of the first's
+// register directly (SDWA dst_sel:WORD_1, dst_unused:UNUSED_PRESERVE), so packing costs nothing.
+// Hand-ordered for gfx950's software-visible hazards (hipcc pads nothing inside asm):
+//   DOT result -> non-DOT reader: 3 instructions in between; sub-dword (SDWA) write -> reader: 1;
+//   DOT -> same-opcode DOT through src2: 0.
+// One statement = 4 output channels (2 packed accumulators) x 1 (pixel, tap).
+__device__ __forceinline__ void stepC4(int &acc01, int &acc23, const int2 x, const int2 w0, const int2 w1, const int2 w2,
+                                       const int2 w3, const int r, const int s)
+{
+    int t0, t1, t2, t3;
+    asm("v_dot2_i32_i16 %2, %6, %14, %16\n\t"
+        "v_dot2_i32_i16 %3, %7, %14, %16\n\t"
+        "v_dot2_i32_i16 %4, %8, %14, %16\n\t"
+        "v_dot2_i32_i16 %5, %9, %14, %16\n\t"
+        "v_dot2_i32_i16 %2, %10, %15, %2\n\t"
+        "v_dot2_i32_i16 %3, %11, %15, %3\n\t"
+        "v_dot2_i32_i16 %4, %12, %15, %4\n\t"
+        "v_dot2_i32_i16 %5, %13, %15, %5\n\t"
+        "v_ashrrev_i32 %2, %17, %2\n\t"
+        "v_ashrrev_i32_sdwa %2, %17, %3 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_ashrrev_i32 %4, %17, %4\n\t"
+        "v_ashrrev_i32_sdwa %4, %17, %5 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n\t"
+        "v_pk_add_i16 %0, %0, %2 clamp\n\t"
+        "v_pk_add_i16 %1, %1, %4 clamp"
+        : "+v"(acc01), "+v"(acc23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "s"(w0.x), "s"(w1.x), "s"(w2.x), "s"(w3.x), "s"(w0.y), "s"(w1.y), "s"(w2.y), "s"(w3.y), "v"(x.x), "v"(x.y),
+          "v"(r), "s"(s));
+}
+
 // Form B (4 instructions per step, needs the tighter bound checked by the host): keep the
 // accumulator pre-shifted, Bv = acc*2^s + round.  Then
 //     Bv' = clamp( ((Bv + p) & ~(2^s-1)) | round )        with bounds  {-32768,32767}*2^s + round
@@ -123,6 +155,7 @@ __device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
 // MODE 0: 32-bit form A, valid when the host proved no intermediate leaves int32.
 // MODE 1: 32-bit form B (pre-shifted accumulator), tighter bound, 4 instructions per step.
 // MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
+// MODE 3: 32-bit form C (packed int16 accumulators, saturating packed add), 3.5 instructions per step.
 // NST: staging registers per thread, 256*NST >= LDS tile items.
 template <int KS, int P, int MODE, int NST>
 __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
@@ -180,6 +213,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p][m] = b0;
         }
+        if (MODE == 3) {  // pack channel pairs (2j, 2j+1) into acc[p][j]; the host proved |bias0| <= 32767
+            int pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pk[j] = ((int)acc[0][2 * j] & 0xffff) | ((int)acc[0][2 * j + 1] << 16);
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[p][j] = (acc_t)pk[j];
+        }
     }
 
     const int r = a.round, s = a.shift;
@@ -232,6 +274,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
                 // form B gets naturally from accumulating into acc.  No instruction is emitted.
                 if (MODE == 0) asm volatile("" : "+v"(x.x) : "v"(chain));
+                if (MODE == 3) {
+                    int a01 = (int)acc[p][0], a23 = (int)acc[p][1], a45 = (int)acc[p][2], a67 = (int)acc[p][3];
+                    stepC4(a01, a23, x, w[0], w[1], w[2], w[3], r_vgpr, s);
+                    stepC4(a45, a67, x, w[4], w[5], w[6], w[7], r_vgpr, s);
+                    acc[p][0] = (acc_t)a01; acc[p][1] = (acc_t)a23; acc[p][2] = (acc_t)a45; acc[p][3] = (acc_t)a67;
+                } else
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     if (MODE == 2) acc[p][m] = (acc_t)step64((long)acc[p][m], x, w[m], a);
@@ -269,6 +317,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             for (int t = 0; t < 4; ++t) {
                 int e = (int)acc[p][g * 4 + t];
                 if (MODE == 1) e >>= s;  // back from the pre-shifted domain
+                if (MODE == 3) {         // unpack channel g*4+t from its pair register
+                    const int pr = (int)acc[p][(g * 4 + t) >> 1];
+                    e = (t & 1) ? (pr >> 16) : (int)(short)(pr & 0xffff);
+                }
                 v[t] = a.leaky ? leaky_i16(e) : e;
             }
             int2 o;

@@ -119,7 +119,8 @@ static ShiftSpec make_shift(int s)  // core_compute.cpp:48-63: magnitude capped 
 // 32-bit exactness: no intermediate of the fast kernel may leave int32.
 //   |p + round| <= maxsum*32768 + round ;  |acc + scaled| <= max(32768,|bias0|) + |p + round|
 // Form B keeps acc*2^s + round in the register:  max(32768,|bias0|)*2^s + round + |p| must fit.
-// Returns 0 (form A), 1 (form B) or 2 (64-bit).
+// Form C packs two int16 accumulators per register and needs every increment to fit int16.
+// Returns 0 (form A), 1 (form B), 3 (form C) or 2 (64-bit); the narrowest legal form wins.
 static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
 {
     if (so < 0) return 2;
@@ -132,12 +133,17 @@ static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
     const long long pmax = (long long)maxsum * 32768;
     if (bias0 > 2147483647LL) return 2;
     int path = 2;
-    if (pmax + round + accmax <= 2147483647LL) path = 0;
-    if ((accmax << o.mag) + round + pmax <= 2147483647LL) path = 1;
-    const char *force = getenv("YOLO2_FORCE_PATH");  // test hook: 0/1 only when legal, 2 always
+    const bool okA = pmax + round + accmax <= 2147483647LL;
+    const bool okB = (accmax << o.mag) + round + pmax <= 2147483647LL;
+    // form C: every t = (p + round) >> s and the shifted bias must fit int16 (and p + round int32)
+    const bool okC = okA && bias0 <= 32767 && ((pmax + round) >> o.mag) <= 32767;
+    if (okA) path = 0;
+    if (okB) path = 1;
+    if (okC) path = 3;
+    const char *force = getenv("YOLO2_FORCE_PATH");  // test hook: a narrower path only when it is legal, 2 always
     if (force) {
         const int f = atoi(force);
-        if (f == 2 || (f == 0 && path != 2)) path = f;
+        if (f == 2 || (f == 0 && okA) || (f == 1 && okB) || (f == 3 && okC)) path = f;
     }
     return path;
 }
@@ -147,7 +153,7 @@ constexpr int kMaxTileItems = 2048;  // 8 staging registers x 256 threads (k_con
 struct ConvPlan {
     int C = 0, N = 0, K = 0, H = 0, W = 0, leaky = 0;
     int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
-    int path = 0;  // 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 2 = 64-bit
+    int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 2 = 64-bit
     int P = 8;
     dim3 grid;
     int lds_bytes = 0;
@@ -158,7 +164,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
 {
     const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
     const int npix = gin.B * gin.H * gin.W;
-    const int maxP = p.path == 1 ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
+    const int maxP = (p.path == 1 || p.path == 3) ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
     if (forceP) {
         p.P = std::min(forceP, maxP);
     } else {
@@ -212,10 +218,12 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
 {
     if (p.K == 3) {
         if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 3) launch_conv_p<3, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<3, 1>(p, in, out, wpk, bias, st);
         else launch_conv_p<3, 0>(p, in, out, wpk, bias, st);
     } else {
         if (p.path == 2) launch_conv_p<1, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 3) launch_conv_p<1, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<1, 1>(p, in, out, wpk, bias, st);
         else launch_conv_p<1, 0>(p, in, out, wpk, bias, st);
     }
@@ -855,6 +863,17 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
         const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
         const int CGout = (kNet[i].n + 3) / 4;
         plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
+    }
+    const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
+    if (fp && atoi(fp) > 0) {
+        for (int i = 0; i < 32; ++i) {
+            if (kNet[i].type != L_CONV) continue;
+            const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+            const Tensor &tout = c->t_out[i];
+            plan_conv(c->plan[i], tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0),
+                      (kNet[i].n + 3) / 4, atoi(fp));
+        }
+        return YOLO2_SUCCESS;
     }
     const char *at = getenv("YOLO2_AUTOTUNE");
     if (!(at && at[0] == '0')) return autotune(c);
