@@ -42,7 +42,8 @@ struct ConvF16Args {
     int KS;                // 1 or 3
 };
 
-constexpr int kBM = 128, kBN = 128, kBK = 32, kLdsRow = 40;  // halves per LDS row (32 + 8 pad)
+constexpr int kBM = 128, kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
+constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
 
 __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
 {
@@ -55,34 +56,48 @@ __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
 
 // act: items of Cp_in halves (pointer at item 0 incl. lead); wh: [N_pad][KK][Cp_in] halves;
 // bias: [N_pad] fp32; out: items of Cp_out halves; out_f32 (optional): dense [B][N][H][W] fp32.
+// BN = 128: 2x2 wavefronts of 64x64;  BN = 64 (layers with <= 64 output channels): 4x1 of 32x64.
+template <int BN, int BK>
 __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                    const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                    float *__restrict__ out_f32, const ConvF16Args a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 As[2][kBM][kLdsRow];
-    __shared__ __attribute__((aligned(16))) _Float16 Bs[2][kBN][kLdsRow];
+    constexpr int WN = BN / 64, WM = 4 / WN;   // wavefront grid
+    constexpr int MT = kBM / WM / 32;          // 32-row MFMA tiles per wavefront along M (2 or 1)
+    constexpr int kBK = BK, kLdsRow = BK + 8;
+    constexpr int CPR = BK / 8;                // 16-byte chunks per staged row (4 or 8)
+    constexpr int RPP = 256 / CPR;             // rows staged per pass of the 256 threads (64 or 32)
+    constexpr int APASS = kBM / RPP, BPASS = BN / RPP;
+    // one LDS arena: K-loop staging (A: 2 x 128 x 40, B: 2 x BN x 40 halves), reused by the epilogue
+    // as a [128][136] fp16 tile so that the output leaves in 16-byte stores
+    constexpr int kStageHalves = 2 * kBM * kLdsRow + 2 * BN * kLdsRow;
+    constexpr int kEpiHalves = kBM * kCtRow;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[kStageHalves > kEpiHalves ? kStageHalves : kEpiHalves];
     __shared__ int fo_s[kBM];
+    _Float16 (*As)[kBM][kLdsRow] = reinterpret_cast<_Float16 (*)[kBM][kLdsRow]>(smem);
+    _Float16 (*Bs)[BN][kLdsRow] = reinterpret_cast<_Float16 (*)[BN][kLdsRow]>(smem + 2 * kBM * kLdsRow);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int HW = a.H * a.W;
     const int q0 = blockIdx.x * kBM;
-    const int n0 = blockIdx.y * kBN;
+    const int n0 = blockIdx.y * BN;
     const int KK = a.KS * a.KS;
 
     if (tid < kBM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
     __syncthreads();
 
-    // staging map: thread -> (row, 16-byte chunk) x 2
-    const int srow = tid >> 2, schunk = tid & 3;
-    const size_t a_base0 = ((size_t)kLead + fo_s[srow]) * a.Cp_in + schunk * 8;
-    const size_t a_base1 = ((size_t)kLead + fo_s[srow + 64]) * a.Cp_in + schunk * 8;
-    const size_t b_base0 = (size_t)(n0 + srow) * KK * a.Cp_in + schunk * 8;
-    const size_t b_base1 = (size_t)(n0 + srow + 64) * KK * a.Cp_in + schunk * 8;
-
-    float16_t acc[2][2];
+    // staging map: thread -> (row, 16-byte chunk), APASS / BPASS rows per thread
+    const int srow = tid / CPR, schunk = tid % CPR;
+    size_t a_base[APASS], b_base[BPASS];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int k = 0; k < APASS; ++k) a_base[k] = ((size_t)kLead + fo_s[srow + k * RPP]) * a.Cp_in + schunk * 8;
+#pragma unroll
+    for (int k = 0; k < BPASS; ++k) b_base[k] = (size_t)(n0 + srow + k * RPP) * KK * a.Cp_in + schunk * 8;
+
+    float16_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -98,81 +113,176 @@ __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ a
         boff = (long)tap * a.Cp_in + c0;
     };
 
-    half8_t ra0, ra1, rb0, rb1;
-    {
+    half8_t ra[APASS], rb[BPASS];
+    auto stage_load = [&](int step) {
         long ao, bo;
-        koff(0, ao, bo);
-        ra0 = *reinterpret_cast<const half8_t *>(act + a_base0 + ao);
-        ra1 = *reinterpret_cast<const half8_t *>(act + a_base1 + ao);
-        rb0 = *reinterpret_cast<const half8_t *>(wh + b_base0 + bo);
-        rb1 = *reinterpret_cast<const half8_t *>(wh + b_base1 + bo);
-        *reinterpret_cast<half8_t *>(&As[0][srow][schunk * 8]) = ra0;
-        *reinterpret_cast<half8_t *>(&As[0][srow + 64][schunk * 8]) = ra1;
-        *reinterpret_cast<half8_t *>(&Bs[0][srow][schunk * 8]) = rb0;
-        *reinterpret_cast<half8_t *>(&Bs[0][srow + 64][schunk * 8]) = rb1;
-    }
+        koff(step, ao, bo);
+#pragma unroll
+        for (int k = 0; k < APASS; ++k) ra[k] = *reinterpret_cast<const half8_t *>(act + a_base[k] + ao);
+#pragma unroll
+        for (int k = 0; k < BPASS; ++k) rb[k] = *reinterpret_cast<const half8_t *>(wh + b_base[k] + bo);
+    };
+    auto stage_write = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < APASS; ++k) *reinterpret_cast<half8_t *>(&As[buf][srow + k * RPP][schunk * 8]) = ra[k];
+#pragma unroll
+        for (int k = 0; k < BPASS; ++k) *reinterpret_cast<half8_t *>(&Bs[buf][srow + k * RPP][schunk * 8]) = rb[k];
+    };
+    stage_load(0);
+    stage_write(0);
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         const bool more = step + 1 < nsteps;
-        if (more) {  // global loads of the next K-step fly while this one is multiplied
-            long ao, bo;
-            koff(step + 1, ao, bo);
-            ra0 = *reinterpret_cast<const half8_t *>(act + a_base0 + ao);
-            ra1 = *reinterpret_cast<const half8_t *>(act + a_base1 + ao);
-            rb0 = *reinterpret_cast<const half8_t *>(wh + b_base0 + bo);
-            rb1 = *reinterpret_cast<const half8_t *>(wh + b_base1 + bo);
-        }
+        if (more) stage_load(step + 1);  // global loads of the next K-step fly while this one is multiplied
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8_t af[2], bf[2];
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            half8_t af[MT], bf[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                af[t] = *reinterpret_cast<const half8_t *>(&As[cur][wm * 64 + t * 32 + frow][kk * 16 + fk]);
+            for (int t = 0; t < MT; ++t)
+                af[t] = *reinterpret_cast<const half8_t *>(&As[cur][wm * (32 * MT) + t * 32 + frow][kk * 16 + fk]);
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
                 bf[t] = *reinterpret_cast<const half8_t *>(&Bs[cur][wn * 64 + t * 32 + frow][kk * 16 + fk]);
-            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            const int nxt = cur ^ 1;
-            *reinterpret_cast<half8_t *>(&As[nxt][srow][schunk * 8]) = ra0;
-            *reinterpret_cast<half8_t *>(&As[nxt][srow + 64][schunk * 8]) = ra1;
-            *reinterpret_cast<half8_t *>(&Bs[nxt][srow][schunk * 8]) = rb0;
-            *reinterpret_cast<half8_t *>(&Bs[nxt][srow + 64][schunk * 8]) = rb1;
-        }
+        if (more) stage_write(cur ^ 1);
         __syncthreads();
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31 (channel), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel)
+    if (out_f32) {  // last layer: dense fp32 [B][N][H][W], straight from the accumulators
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (ch >= a.N) continue;
+            const float bv = bias[ch];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int q = q0 + row;
+                    if (q >= a.npix) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (a.leaky && v < 0.f) v *= 0.1f;
+                    const int b = q / HW, rem = q - b * HW;
+                    out_f32[((size_t)b * a.N + ch) * HW + rem] = v;
+                }
+        }
+        return;
+    }
+    // fp16 items: bias + leaky in fp32, transpose through LDS, leave in 16-byte (8-channel) stores
+    _Float16 (*Ct)[kCtRow] = reinterpret_cast<_Float16 (*)[kCtRow]>(smem);   // the K loop ended with a barrier
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int ch = n0 + wn * 64 + j * 32 + (lane & 31);
-        if (ch >= a.n_store) continue;
-        const float bv = bias[ch];
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        const float bv = bias[n0 + col];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int q = q0 + row;
-                if (q >= a.npix) continue;
+                const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = acc[i][j][r] + bv;
                 if (a.leaky && v < 0.f) v *= 0.1f;
-                if (out_f32) {
-                    if (ch < a.N) {
-                        const int b = q / HW, rem = q - b * HW;
-                        out_f32[((size_t)b * a.N + ch) * HW + rem] = v;
-                    }
-                } else {
-                    out[((size_t)kLead + fo_s[row]) * a.Cp_out + a.out_ch_off + ch] = (_Float16)v;
-                }
+                Ct[row][col] = (_Float16)v;
             }
+    }
+    __syncthreads();
+    constexpr int CH = BN / 8;               // 16-byte chunks per pixel row
+    constexpr int ROWS_PER_PASS = 256 / CH;  // 16 or 32
+    const int chunk = tid % CH, r0 = tid / CH;
+    const int ch0 = n0 + chunk * 8;
+    if (ch0 < a.n_store) {
+#pragma unroll
+        for (int rr = 0; rr < kBM / ROWS_PER_PASS; ++rr) {
+            const int row = r0 + rr * ROWS_PER_PASS;
+            if (q0 + row >= a.npix) continue;
+            const half8_t v = *reinterpret_cast<const half8_t *>(&Ct[row][chunk * 8]);
+            *reinterpret_cast<half8_t *>(out + ((size_t)kLead + fo_s[row]) * a.Cp_out + a.out_ch_off + ch0) = v;
+        }
+    }
+}
+
+// Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:
+// K = 27 is too thin for the matrix cores, and the 416x416x32 intermediate is never needed again
+// (yolov2.cfg: layer 1 is its only consumer), so this kernel keeps it in registers.  One lane owns
+// one pooled pixel = a 2x2 block of conv outputs x 16 channels (blockIdx.y picks the channel half)
+// = 64 fp32 accumulators; the 27x32 weights are read from LDS as broadcast 16-byte reads;
+// output = layer-1 items (32 halves).
+// w0: [27][32] fp32 (k = c*9 + i*3 + j), bias0: [32] fp32.
+__global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restrict__ frames, const float *__restrict__ w0,
+                                                         const float *__restrict__ bias0, _Float16 *__restrict__ out,
+                                                         int B, int H, int W, int oWp, int oPL)
+{
+    __shared__ __attribute__((aligned(16))) float ws[27 * 32 + 32];
+    for (int i = threadIdx.x; i < 27 * 32 + 32; i += 256) ws[i] = i < 27 * 32 ? w0[i] : bias0[i - 27 * 32];
+    __syncthreads();
+    const int OH = H / 2, OW = W / 2;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= B * OH * OW) return;
+    const int b = q / (OH * OW), r = q - b * (OH * OW), oy = r / OW, ox = r - oy * OW;
+    const int nh = blockIdx.y * 16;   // channel half
+    float acc[4][16];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int n = 0; n < 16; ++n) acc[p][n] = ws[27 * 32 + nh + n];
+    const size_t HWs = (size_t)H * W;
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        float in[4][4];   // the 4x4 input patch of this 2x2 output block
+#pragma unroll
+        for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+            for (int xx = 0; xx < 4; ++xx) {
+                const int sy = 2 * oy + yy - 1, sx = 2 * ox + xx - 1;
+                in[yy][xx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? frames[((size_t)b * 3 + c) * HWs + (size_t)sy * W + sx] : 0.f;
+            }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float4 *wr = reinterpret_cast<const float4 *>(&ws[(c * 9 + i * 3 + j) * 32 + nh]);
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) {
+                    const float4 wv = wr[n4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const float xv = in[(p >> 1) + i][(p & 1) + j];
+                        acc[p][n4 * 4 + 0] = fmaf(wv.x, xv, acc[p][n4 * 4 + 0]);
+                        acc[p][n4 * 4 + 1] = fmaf(wv.y, xv, acc[p][n4 * 4 + 1]);
+                        acc[p][n4 * 4 + 2] = fmaf(wv.z, xv, acc[p][n4 * 4 + 2]);
+                        acc[p][n4 * 4 + 3] = fmaf(wv.w, xv, acc[p][n4 * 4 + 3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the weight reads of later taps from being hoisted (register pressure)
+            }
+    }
+    half8_t *dst = reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + nh);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int n = k * 8 + e;
+            float m = -3.0e38f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float v = acc[p][n];
+                v = v < 0.f ? v * 0.1f : v;          // leaky, then pool (same order as the layer pipeline)
+                // the layer-0 tensor is fp16 in the unfused pipeline: round before the max like it does
+                m = fmaxf(m, (float)(_Float16)v);
+            }
+            o[e] = (_Float16)m;
+        }
+        dst[k] = o;
     }
 }
 
@@ -265,6 +375,18 @@ __global__ void k_pack_weights_f16(const float *__restrict__ src, _Float16 *__re
         v = src[(long)m0 * C * KK + (long)tm_min * n0 * KK + (long)tap * tm_min * tn_min + tm * tn_min + tn];
     }
     dst[t] = (_Float16)v;
+}
+
+// layer-0 weights for k_conv0_pool_f16: weights_reorg fp32 (C=3, N=32, 3x3) -> w0[k = c*9 + tap][n]
+__global__ void k_pack_w0_f32(const float *__restrict__ src, const float *__restrict__ bias_src, float *__restrict__ w0,
+                              float *__restrict__ b0)
+{
+    const int t = threadIdx.x + blockIdx.x * blockDim.x;
+    if (t < 32) b0[t] = bias_src[t];
+    if (t >= 27 * 32) return;
+    const int n = t & 31, k = t >> 5, c = k / 9, tap = k - c * 9;
+    // block (m0 = 0, n0 = 0): [tap][32][3]
+    w0[t] = src[(long)tap * 32 * 3 + n * 3 + c];
 }
 
 }  // namespace y2

@@ -574,6 +574,7 @@ struct yolo2_hip_ctx {
     bool f16_loaded = false;
     _Float16 *wh = nullptr;
     float *biasf = nullptr;
+    float *w0f = nullptr;  // layer 0: [27][32] fp32 weights + [32] bias for the fused conv0+pool kernel
     long wh_off[YOLO2_N_CONV], biasf_off[YOLO2_N_CONV];
     int f16_batch = 0;
     HalfTensor h_in, h_out[32], h_cat;
@@ -633,6 +634,7 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
     free_f16_activations(c);
     if (c->wh) (void)hipFree(c->wh);
     if (c->biasf) (void)hipFree(c->biasf);
+    if (c->w0f) (void)hipFree(c->w0f);
     if (c->wpk) (void)hipFree(c->wpk);
     if (c->bias_pk) (void)hipFree(c->bias_pk);
     if (c->ev_made)
@@ -1061,7 +1063,7 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
     for (int i = 0; i < 32; ++i)
         if (kNet[i].type == L_CONV) {
             const LayerDesc &l = kNet[i];
-            const int npad = round_up(l.n, kBN);
+            const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN);
             c->wh_off[ord] = wtot;
             c->biasf_off[ord] = btot;
             wtot += i == 0 ? (long)npad * 32 : (long)npad * l.size * l.size * round_up(l.c, 32);
@@ -1084,7 +1086,7 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
     for (int i = 0; i < 32; ++i) {
         const LayerDesc &l = kNet[i];
         if (l.type != L_CONV) continue;
-        const int npad = round_up(l.n, kBN), KK = l.size * l.size;
+        const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN), KK = l.size * l.size;
         const int Cp = i == 0 ? 32 : round_up(l.c, 32);
         const long n = (long)npad * (i == 0 ? 1 : KK) * Cp;
         hipLaunchKernelGGL(k_pack_weights_f16, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
@@ -1093,6 +1095,8 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
         boff += yolo2_bias_len[ord];
         ord++;
     }
+    if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
+    hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
     HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
     (void)hipFree(wd);
@@ -1115,9 +1119,8 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
     if (c->f16_batch == B) return YOLO2_SUCCESS;
     free_f16_activations(c);
     int rc;
-    if ((rc = alloc_half(c->h_in, 27, 32, 416, 416, B))) return rc;      // layer-0 im2col items
     if ((rc = alloc_half(c->h_cat, 1280, 1280, 13, 13, B))) return rc;
-    for (int i = 0; i < 30; ++i) {
+    for (int i = 1; i < 30; ++i) {   // layer 0's 416x416x32 tensor never exists: conv0+pool are fused
         const LayerDesc &l = kNet[i];
         if (l.type == L_CONV && i != 24) {
             if ((rc = alloc_half(c->h_out[i], l.n, round_up(l.n, 32), l.h, l.w, B))) return rc;
@@ -1144,14 +1147,16 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     const int B = batch;
     hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
     if (ev) (void)hipEventRecord(ev[0], st);
-    {
-        const auto &g = c->h_in;
-        hipLaunchKernelGGL(k_pack_input_f16, dim3(blocks_for((long)B * g.H * g.W, 256)), dim3(256), 0, st,
-                           (const float *)(uintptr_t)frames_dev, g.d, B, g.H, g.W, g.Wp, g.PL);
+    {   // layers 0+1 fused: conv 3->32 + leaky + 2x2 pool straight from the float frames
+        const auto &g = c->h_out[1];
+        hipLaunchKernelGGL(k_conv0_pool_f16, dim3(blocks_for((long)B * g.H * g.W, 256), 2), dim3(256), 0, st,
+                           (const float *)(uintptr_t)frames_dev, (const float *)c->w0f, (const float *)(c->w0f + 27 * 32), g.d, B,
+                           416, 416, g.Wp, g.PL);
+        if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
     }
-    int ord = 0;
-    const yolo2_hip_ctx::HalfTensor *cur = &c->h_in;
-    for (int i = 0; i < 32; ++i) {
+    int ord = 1;
+    const yolo2_hip_ctx::HalfTensor *cur = &c->h_out[1];
+    for (int i = 2; i < 32; ++i) {
         const LayerDesc &l = kNet[i];
         switch (l.type) {
         case L_CONV: {
@@ -1166,11 +1171,22 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             a.n_store = i == 30 ? l.n : round_up(l.n, 32);
             a.npix = B * l.h * l.w;
             a.leaky = l.leaky;
-            a.KS = i == 0 ? 1 : l.size;   // layer 0 runs as a 1x1 conv over im2col items
-            const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, kBN) / kBN);
-            hipLaunchKernelGGL(k_conv_f16, grid, dim3(256), 0, st, (const _Float16 *)tin->d, (const _Float16 *)(c->wh + c->wh_off[ord]),
-                               (const float *)(c->biasf + c->biasf_off[ord]), i == 30 ? (_Float16 *)nullptr : tout.d,
-                               i == 30 ? (float *)(uintptr_t)region_dev : (float *)nullptr, a);
+            a.KS = l.size;
+            const _Float16 *wp = (const _Float16 *)(c->wh + c->wh_off[ord]);
+            const float *bp = (const float *)(c->biasf + c->biasf_off[ord]);
+            _Float16 *op = i == 30 ? (_Float16 *)nullptr : tout.d;
+            float *of = i == 30 ? (float *)(uintptr_t)region_dev : (float *)nullptr;
+            const bool bk64 = a.Cp_in % 64 == 0;   // K-step of 64 channels wherever the item size allows it
+            const _Float16 *ip = (const _Float16 *)tin->d;
+            if (l.n <= 64) {
+                const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, 64) / 64);
+                if (bk64) hipLaunchKernelGGL((k_conv_f16<64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else hipLaunchKernelGGL((k_conv_f16<64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+            } else {
+                const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, kBN) / kBN);
+                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else hipLaunchKernelGGL((k_conv_f16<128, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+            }
             if (i != 30) cur = &c->h_out[i];
             ord++;
             break;
