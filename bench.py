@@ -188,8 +188,11 @@ def main():
         sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # YOLO2_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (rehearses the multi-GPU code path on a 1-GPU box)
+    use_dist = world > 1 or os.environ.get("YOLO2_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
@@ -214,7 +217,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -227,7 +230,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -269,7 +272,7 @@ def main():
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"YOLOv2 INT16 416x416 batch={B} per GPU, bit-exact int16 conv/bias/leaky/maxpool/reorg path",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded x{world}, weights broadcast once",
-                       "conv_paths": paths},
+                       "conv_paths": paths, "conv_path_block_counts": ctx.layer_path_counts()},
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -282,7 +285,7 @@ def main():
             gpu_region0 = region[0].cpu().numpy()
             result["cpu_baseline"] = cpu_baseline(model, frames[0].cpu().numpy(), gpu_region0)
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -134,6 +134,10 @@ int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_
  * loader picks the narrowest one it can PROVE exact for the weights and Q values at hand
  * (csrc/kernels_int16.hpp explains the forms). */
 int yolo2_hip_layer_path(yolo2_hip_ctx *ctx, int conv_ordinal);
+/* The form is chosen per block of 32 output channels (a few large-weight channels must not slow
+ * a whole layer down): layer_path() reports the form most blocks use, this the count per form
+ * (index = the codes above). */
+int yolo2_hip_layer_path_counts(yolo2_hip_ctx *ctx, int conv_ordinal, int counts[4]);
 
 /* (Re)allocates the activation tensors for exactly `batch` frames per call. */
 int yolo2_hip_set_batch(yolo2_hip_ctx *ctx, int batch);

@@ -251,6 +251,32 @@ def test_extreme_weights_select_wide_path():
     ctx.close()
 
 
+def test_mixed_forms_inside_one_layer():
+    """A few large-weight output channels must only demote THEIR block of 32 channels: the layer is
+    split into one launch per arithmetic form, and the result stays bit-exact."""
+    model = synth.SynthModel(seed=1)
+    rng = np.random.default_rng(11)
+    # ord 7 (128->256 3x3): blow up channels 40..43 (block 1) moderately, channel 200 (block 6) to the int16 limits
+    w = model.w_nat[7].astype(np.int32)
+    w[40:44] *= 12
+    w[200] = rng.choice(np.array([-32768, 32767]), w[200].shape)
+    model.w_nat[7] = np.clip(w, -32768, 32767).astype(np.int16)
+    l = net.CONVS[7]
+    model.w_reorg[7] = synth.reorg_weights(model.w_nat[7], l.c, l.n, l.size)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    counts = ctx.layer_path_counts()
+    assert sum(counts[7]) == 8 and counts[7][3] == 6 and counts[7][2] == 1, counts[7]   # 6 blocks form C, one 64-bit, one A/B
+    assert all(sum(c) == (l.n + 31) // 32 for c, l in zip(counts, net.CONVS)), counts   # every block is in exactly one launch
+    frames = synth.frames(21, 2)
+    region, _ = ctx.run_batch_host(frames)
+    orclib.oracle().orc_set_threads(16)
+    for f in range(2):
+        ri, _, _ = orclib.forward_i16(model, frames[f])
+        assert np.array_equal(region[f].reshape(-1), ri), _diagnose(ctx, model, frames[f], f)
+    ctx.close()
+
+
 def test_batch64_properties():
     """C3 size (batch 64): (a) frame k of a batch equals the same frame run alone (frames are
     independent: no cross-frame state), (b) two runs are identical, (c) a permuted batch gives

@@ -238,32 +238,55 @@ __global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restri
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         float in[4][4];   // the 4x4 input patch of this 2x2 output block
+        // branch-free: clamped addresses are always valid, out-of-image taps are zeroed afterwards,
+        // so the 16 loads issue back to back instead of one latency-exposed load per guarded branch
+        const float *plane = frames + ((size_t)b * 3 + c) * HWs;
 #pragma unroll
         for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
             for (int xx = 0; xx < 4; ++xx) {
                 const int sy = 2 * oy + yy - 1, sx = 2 * ox + xx - 1;
-                in[yy][xx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? frames[((size_t)b * 3 + c) * HWs + (size_t)sy * W + sx] : 0.f;
+                in[yy][xx] = plane[(size_t)min(max(sy, 0), H - 1) * W + min(max(sx, 0), W - 1)];
             }
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+        for (int yy = 0; yy < 4; ++yy)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const float4 *wr = reinterpret_cast<const float4 *>(&ws[(c * 9 + i * 3 + j) * 32 + nh]);
+            for (int xx = 0; xx < 4; ++xx) {
+                const int sy = 2 * oy + yy - 1, sx = 2 * ox + xx - 1;
+                in[yy][xx] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? in[yy][xx] : 0.f;
+            }
+        // weights of tap t+1 are read from LDS while tap t is multiplied (one tap of lookahead:
+        // a fence per tap keeps hipcc from hoisting all 27 taps' reads and blowing the register file)
+        float4 wcur[4], wnxt[4];
+        {
+            const float4 *wr = reinterpret_cast<const float4 *>(&ws[(c * 9) * 32 + nh]);
 #pragma unroll
-                for (int n4 = 0; n4 < 4; ++n4) {
-                    const float4 wv = wr[n4];
+            for (int n4 = 0; n4 < 4; ++n4) wcur[n4] = wr[n4];
+        }
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const float xv = in[(p >> 1) + i][(p & 1) + j];
-                        acc[p][n4 * 4 + 0] = fmaf(wv.x, xv, acc[p][n4 * 4 + 0]);
-                        acc[p][n4 * 4 + 1] = fmaf(wv.y, xv, acc[p][n4 * 4 + 1]);
-                        acc[p][n4 * 4 + 2] = fmaf(wv.z, xv, acc[p][n4 * 4 + 2]);
-                        acc[p][n4 * 4 + 3] = fmaf(wv.w, xv, acc[p][n4 * 4 + 3]);
-                    }
+        for (int t = 0; t < 9; ++t) {
+            const int i = t / 3, j = t % 3;
+            if (t < 8) {
+                const float4 *wr = reinterpret_cast<const float4 *>(&ws[(c * 9 + t + 1) * 32 + nh]);
+#pragma unroll
+                for (int n4 = 0; n4 < 4; ++n4) wnxt[n4] = wr[n4];
+            }
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) {
+                const float4 wv = wcur[n4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float xv = in[(p >> 1) + i][(p & 1) + j];
+                    acc[p][n4 * 4 + 0] = fmaf(wv.x, xv, acc[p][n4 * 4 + 0]);
+                    acc[p][n4 * 4 + 1] = fmaf(wv.y, xv, acc[p][n4 * 4 + 1]);
+                    acc[p][n4 * 4 + 2] = fmaf(wv.z, xv, acc[p][n4 * 4 + 2]);
+                    acc[p][n4 * 4 + 3] = fmaf(wv.w, xv, acc[p][n4 * 4 + 3]);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // keep the weight reads of later taps from being hoisted (register pressure)
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) wcur[n4] = wnxt[n4];
+        }
     }
     half8_t *dst = reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + nh);
 #pragma unroll

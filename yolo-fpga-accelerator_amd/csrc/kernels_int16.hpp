@@ -40,6 +40,8 @@ struct ConvArgs {
     int bs_right, bs_left, bs_mag;  // bias shift (exact path computes it itself)
     int leaky;
     int lt_max;                // LDS tile capacity in items
+    const int *mb_list;        // optional: blockIdx.y -> output-channel block (a layer whose blocks need
+                               // different arithmetic forms is launched once per form); nullptr = identity
 };
 
 // core_compute.cpp:191-197: x<0 ? x/10 (C division, toward zero) : x.  For u in [1,32768]
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = blockIdx.y;
+    const int mb = a.mb_list ? a.mb_list[blockIdx.y] : (int)blockIdx.y;
     const int HW = a.H * a.W;
     const int q0 = blockIdx.x * T;
     const int qlast = min(q0 + T, a.npix) - 1;
@@ -473,6 +475,23 @@ __global__ void k_weight_bound(const short *__restrict__ wpk, long n_quads, int 
     }
     for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
     if ((threadIdx.x & 63) == 0) atomicMax(result, best);
+}
+
+// Same bound per output-channel block of 32 (one workgroup per block): lets the loader pick the
+// arithmetic form per block, so a few large-weight channels do not slow the whole layer down.
+__global__ void k_weight_bound_mb(const short *__restrict__ wpk, long quads_per_mb, int *__restrict__ result)
+{
+    __shared__ int red[4];
+    const short *base = wpk + (long)blockIdx.x * quads_per_mb * 4;
+    int best = 0;
+    for (long t = threadIdx.x; t < quads_per_mb; t += blockDim.x) {
+        const short *w = base + t * 4;
+        best = max(best, abs((int)w[0]) + abs((int)w[1]) + abs((int)w[2]) + abs((int)w[3]));
+    }
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) result[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
 }
 
 // ------------------------------------------------------------------ generic reference-layout kernels

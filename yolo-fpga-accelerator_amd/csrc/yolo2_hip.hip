@@ -155,6 +155,7 @@ struct ConvPlan {
     int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
     int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 2 = 64-bit
     int P = 8;
+    int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
     dim3 grid;
     int lds_bytes = 0;
     ConvArgs args;
@@ -170,12 +171,13 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     } else {
         p.P = maxP;
         // small problems (single frame): fewer pixels per lane -> more workgroups
-        while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * ((p.N + 31) / 32) < 1024) p.P >>= 1;
+        while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * (p.mb_count ? p.mb_count : (p.N + 31) / 32) < 1024) p.P >>= 1;
     }
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
     const int T = 64 * p.P;
     ConvArgs &a = p.args;
+    // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
     a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
     a.CGin = gin.CG;
     a.CGout = CGout;
@@ -190,7 +192,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
     p.lds_bytes = a.lt_max * 8 * 2;  // double-buffered input tile
-    p.grid = dim3((npix + T - 1) / T, (p.N + 31) / 32, 1);
+    p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
 }
 
 template <int KS, int MODE, int P>
@@ -495,6 +497,7 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
     if ((rc = max_abs_i16_dev(beta, ofm_num, &maxb))) return rc;
 
     ConvPlan p;
+    p.args.mb_list = nullptr;
     p.C = ifm_num; p.N = ofm_num; p.K = ksize; p.H = input_h; p.W = input_w; p.leaky = is_nl ? 1 : 0;
     p.Qw = qw; p.Qa_in = qa_in; p.Qa_out = qa_out; p.Qb = qb;
     p.path = choose_path(so, sb, maxsum, maxb);
@@ -561,7 +564,11 @@ struct yolo2_hip_ctx {
     long wpk_off[YOLO2_N_CONV], bias_off[YOLO2_N_CONV];
     int maxsum[YOLO2_N_CONV], maxbias[YOLO2_N_CONV];
     std::vector<int> weight_q, bias_q, act_q;
-    ConvPlan plan[32];
+    ConvPlan plan[32];                 // per conv layer: the launch covering most output-channel blocks
+    std::vector<ConvPlan> extra[32];   // further launches for blocks that need another arithmetic form
+    std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV];
+    int *mb_lists = nullptr;           // device: block index lists of all split layers
+    int path_counts[YOLO2_N_CONV][4];
     int reorg_shift = 0, final_q = 0;
     int batch = 0;
     Tensor t_in, t_out[32], t_cat;
@@ -637,6 +644,7 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
     if (c->w0f) (void)hipFree(c->w0f);
     if (c->wpk) (void)hipFree(c->wpk);
     if (c->bias_pk) (void)hipFree(c->bias_pk);
+    if (c->mb_lists) (void)hipFree(c->mb_lists);
     if (c->ev_made)
         for (auto &slot : c->ev)
             for (auto &e : slot) (void)hipEventDestroy(e);
@@ -644,8 +652,9 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
 }
 
 // Resolve the per-layer Q values exactly like the layer loop does (yolo2_model.cpp:290-340, 379-399).
-static void resolve_q(yolo2_hip_ctx *c)
+static int resolve_q(yolo2_hip_ctx *c)
 {
+    std::vector<int> lists;   // concatenated block lists of split layers
     const int na = (int)c->act_q.size();
     int current_Qa = na ? c->act_q[0] : 0, route24_q = 0, pending = -1, ord = 0;
     c->reorg_shift = 0;
@@ -662,7 +671,33 @@ static void resolve_q(yolo2_hip_ctx *c)
             current_Qa = p.Qa_out;
             if (i == 24) route24_q = current_Qa;
             pending = -1;
-            p.path = choose_path(p.Qa_in + p.Qw - p.Qa_out, p.Qb - p.Qa_out, c->maxsum[ord], c->maxbias[ord]);
+            // arithmetic form per block of 32 output channels; launches are grouped by form
+            const int MB = (l.n + 31) / 32, so = p.Qa_in + p.Qw - p.Qa_out, sb = p.Qb - p.Qa_out;
+            std::vector<int> groups[4];
+            for (int mb = 0; mb < MB; ++mb) groups[choose_path(so, sb, c->maxsum_mb[ord][mb], c->maxbias_mb[ord][mb])].push_back(mb);
+            int dom = 0;
+            for (int k = 0; k < 4; ++k) {
+                c->path_counts[ord][k] = (int)groups[k].size();
+                if (groups[k].size() > groups[dom].size()) dom = k;
+            }
+            c->extra[i].clear();
+            p.args.mb_list = nullptr;
+            p.mb_count = 0;
+            p.path = dom;
+            if ((int)groups[dom].size() != MB) {
+                p.mb_count = (int)groups[dom].size();
+                p.args.mb_list = (const int *)(uintptr_t)lists.size();   // offset for now, pointer once uploaded
+                lists.insert(lists.end(), groups[dom].begin(), groups[dom].end());
+                for (int k = 0; k < 4; ++k) {
+                    if (k == dom || groups[k].empty()) continue;
+                    ConvPlan e = p;
+                    e.path = k;
+                    e.mb_count = (int)groups[k].size();
+                    e.args.mb_list = (const int *)(uintptr_t)lists.size();
+                    lists.insert(lists.end(), groups[k].begin(), groups[k].end());
+                    c->extra[i].push_back(e);
+                }
+            }
             ord++;
         } else if (l.type == L_REORG) {
             if (route24_q > 0) {
@@ -674,6 +709,18 @@ static void resolve_q(yolo2_hip_ctx *c)
         }
     }
     c->final_q = current_Qa;
+    if (c->mb_lists) (void)hipFree(c->mb_lists);
+    c->mb_lists = nullptr;
+    if (!lists.empty()) {
+        HIP_TRY(hipMalloc((void **)&c->mb_lists, lists.size() * sizeof(int)), YOLO2_MMAP_ERROR);
+        HIP_TRY(hipMemcpy(c->mb_lists, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+        for (int i = 0; i < 32; ++i) {
+            if (kNet[i].type != L_CONV || !c->plan[i].mb_count) continue;
+            c->plan[i].args.mb_list = c->mb_lists + (uintptr_t)c->plan[i].args.mb_list;
+            for (auto &e : c->extra[i]) e.args.mb_list = c->mb_lists + (uintptr_t)e.args.mb_list;
+        }
+    }
+    return YOLO2_SUCCESS;
 }
 
 static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, const short *b_dev, size_t n_bias,
@@ -703,9 +750,15 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
     HIP_TRY(hipMalloc((void **)&c->wpk, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&c->bias_pk, (size_t)btot * 2), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMemset(c->bias_pk, 0, (size_t)btot * 2), YOLO2_DMA_ERROR);
-    int *bound = nullptr;
+    int *bound = nullptr, *bound_mb = nullptr;
+    int mb_total = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) mb_total += (kNet[i].n + 31) / 32;
     HIP_TRY(hipMalloc((void **)&bound, sizeof(int) * YOLO2_N_CONV), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bound_mb, sizeof(int) * mb_total), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMemset(bound, 0, sizeof(int) * YOLO2_N_CONV), YOLO2_DMA_ERROR);
+    int mb_off = 0;
+    std::vector<int> mb_offs;
     std::vector<short> hb(YOLO2_N_BIAS);
     HIP_TRY(hipMemcpy(hb.data(), b_dev, (size_t)YOLO2_N_BIAS * 2, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
     long woff = 0, boff = 0;
@@ -718,10 +771,20 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
                            c->wpk + c->wpk_off[ord], l.c, l.n, l.size * l.size);
         hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(n / 4, 256), 1024)), dim3(256), 0, nullptr,
                            (const short *)(c->wpk + c->wpk_off[ord]), n / 4, bound + ord);
+        const int MB = (l.n + 31) / 32;
+        hipLaunchKernelGGL(k_weight_bound_mb, dim3(MB), dim3(256), 0, nullptr, (const short *)(c->wpk + c->wpk_off[ord]),
+                           n / 4 / MB, bound_mb + mb_off);
+        mb_offs.push_back(mb_off);
+        mb_off += MB;
         HIP_TRY(hipMemcpyAsync(c->bias_pk + c->bias_off[ord], b_dev + boff, (size_t)l.n * 2, hipMemcpyDeviceToDevice, nullptr),
                 YOLO2_DMA_ERROR);
         int mb = 0;
-        for (int k = 0; k < l.n; ++k) mb = std::max(mb, std::abs((int)hb[boff + k]));
+        c->maxbias_mb[ord].assign(MB, 0);
+        for (int k = 0; k < l.n; ++k) {
+            const int v = std::abs((int)hb[boff + k]);
+            mb = std::max(mb, v);
+            c->maxbias_mb[ord][k / 32] = std::max(c->maxbias_mb[ord][k / 32], v);
+        }
         c->maxbias[ord] = mb;
         woff += yolo2_weight_len[ord];
         boff += yolo2_bias_len[ord];
@@ -729,8 +792,23 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
     }
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
     HIP_TRY(hipMemcpy(c->maxsum, bound, sizeof(int) * YOLO2_N_CONV, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    {
+        std::vector<int> hm(mb_total);
+        HIP_TRY(hipMemcpy(hm.data(), bound_mb, sizeof(int) * mb_total, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+        int o = 0;
+        for (int i = 0; i < 32; ++i)
+            if (kNet[i].type == L_CONV) {
+                const int MB = (kNet[i].n + 31) / 32;
+                c->maxsum_mb[o].assign(hm.begin() + mb_offs[o], hm.begin() + mb_offs[o] + MB);
+                o++;
+            }
+    }
     (void)hipFree(bound);
-    resolve_q(c);
+    (void)hipFree(bound_mb);
+    {
+        const int rq = resolve_q(c);
+        if (rq) return rq;
+    }
     c->weights_loaded = true;
     if (c->batch) {  // re-plan for the new Q values
         const int b = c->batch;
@@ -784,6 +862,13 @@ extern "C" int yolo2_hip_layer_path(yolo2_hip_ctx *c, int ord)
     return -1;
 }
 
+extern "C" int yolo2_hip_layer_path_counts(yolo2_hip_ctx *c, int ord, int counts[4])
+{
+    if (!c || !c->weights_loaded || ord < 0 || ord >= YOLO2_N_CONV || !counts) return YOLO2_ERROR;
+    for (int k = 0; k < 4; ++k) counts[k] = c->path_counts[ord][k];
+    return YOLO2_SUCCESS;
+}
+
 static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
 {
     t.g = make_geom(C, H, W, B);
@@ -808,25 +893,29 @@ static int autotune(yolo2_hip_ctx *c)
         const Tensor &tout = c->t_out[i];
         const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
         const int CGout = (kNet[i].n + 3) / 4;
-        float best = 1e30f;
-        int bestP = c->plan[i].P;
-        for (int P : {8, 4, 2, 1}) {
-            ConvPlan cand = c->plan[i];
-            plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
-            if (cand.P != P) continue;  // not available for this path / shape
-            float tmin = 1e30f;
-            for (int rep = 0; rep < 2; ++rep) {
-                (void)hipEventRecord(e0, nullptr);
-                launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr);
-                (void)hipEventRecord(e1, nullptr);
-                HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
-                float t = 0;
-                HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
-                tmin = std::min(tmin, t);
+        std::vector<ConvPlan *> subs{&c->plan[i]};
+        for (auto &e : c->extra[i]) subs.push_back(&e);
+        for (ConvPlan *sp : subs) {
+            float best = 1e30f;
+            int bestP = sp->P;
+            for (int P : {8, 4, 2, 1}) {
+                ConvPlan cand = *sp;
+                plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
+                if (cand.P != P) continue;  // not available for this path / shape
+                float tmin = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    (void)hipEventRecord(e0, nullptr);
+                    launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr);
+                    (void)hipEventRecord(e1, nullptr);
+                    HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
+                    float t = 0;
+                    HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
+                    tmin = std::min(tmin, t);
+                }
+                if (tmin < best) { best = tmin; bestP = P; }
             }
-            if (tmin < best) { best = tmin; bestP = P; }
+            plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
-        plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         ord++;
     }
     (void)hipEventDestroy(e0);
@@ -865,6 +954,7 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
         const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
         const int CGout = (kNet[i].n + 3) / 4;
         plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
+        for (auto &e : c->extra[i]) plan_conv(e, tin.g, tout.g.cg_stride, out_base, CGout);
     }
     const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
     if (fp && atoi(fp) > 0) {
@@ -874,6 +964,8 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
             const Tensor &tout = c->t_out[i];
             plan_conv(c->plan[i], tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0),
                       (kNet[i].n + 3) / 4, atoi(fp));
+            for (auto &e : c->extra[i])
+                plan_conv(e, tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0), (kNet[i].n + 3) / 4, atoi(fp));
         }
         return YOLO2_SUCCESS;
     }
@@ -964,6 +1056,8 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
             const Tensor *tin = i == 26 ? &c->t_out[16] : (i == 29 ? &c->t_cat : cur);
             launch_conv(c->plan[i], tin->d, c->t_out[i].d, (const int2 *)(c->wpk + c->wpk_off[ord]),
                         c->bias_pk + c->bias_off[ord], st);
+            for (const auto &e : c->extra[i])   // blocks of this layer that need another arithmetic form
+                launch_conv(e, tin->d, c->t_out[i].d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], st);
             cur = &c->t_out[i];
             ord++;
             break;

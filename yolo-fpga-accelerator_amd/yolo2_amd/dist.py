@@ -43,7 +43,7 @@ def broadcast_model(model, device: torch.device, src: int = 0):
         w = torch.empty(net.N_WEIGHTS, dtype=torch.int16, device=device)
         b = torch.empty(net.N_BIAS, dtype=torch.int16, device=device)
         q = torch.empty(3 + 3 * 64, dtype=torch.int32, device=device)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         # byte views: gloo (CPU tests) has no int16 collectives; on nccl (= RCCL) it is the same copy
         dist.broadcast(w.view(torch.uint8), src)   # 101,883,584 B: the one large collective of the job
         dist.broadcast(b.view(torch.uint8), src)
