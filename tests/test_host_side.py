@@ -95,3 +95,27 @@ def test_pnm_loader(tmp_path):
     assert list(whc) == [5, 7, 3]
     assert np.array_equal(out.reshape(3, 7, 5), img.transpose(2, 0, 1).astype(np.float32) / np.float32(255))
     assert orclib.host().y2h_load_pnm(b"/nonexistent.ppm", whc, out, out.size) == -1
+
+
+def test_own_weight_gen_matches_reference_tool_and_python(tmp_path):
+    """Our C++ yolov2_weight_gen == yolo2_amd.synth.reorg_weights == (where built) the reference's
+    own yolov2_weight_gen, byte for byte, int16 (with the per-layer file pad) and fp32."""
+    from yolo2_amd import synth
+    subprocess.run(["make", "-s", "-C", PKG, os.path.join(PKG, "yolov2_weight_gen")], check=True)
+    m = synth.SynthModel(seed=6)
+    m.write_files(str(tmp_path / "weights"), natural=True)
+    cfg = os.path.join(PKG, "config", "yolov2.cfg")
+    for prec, src, ours in (("int16", "weight_int16.bin", "weights_reorg_int16.bin"), ("fp32", "weights.bin", "weights_reorg.bin")):
+        out = tmp_path / f"mine_{prec}.bin"
+        r = subprocess.run([os.path.join(PKG, "yolov2_weight_gen"), "--cfg", cfg, "--weights", str(tmp_path / "weights" / src),
+                            "--out", str(out), "--precision", prec], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(out, "rb").read() == open(tmp_path / "weights" / ours, "rb").read(), prec
+        ref_tool = os.path.join(orclib.REF_DIR, "yolov2_weight_gen")
+        if os.path.exists(ref_tool) and os.path.exists("/root/reference/config/yolov2.cfg"):
+            ref_out = tmp_path / f"ref_{prec}.bin"
+            subprocess.run([ref_tool, "--cfg", "/root/reference/config/yolov2.cfg", "--weights", str(tmp_path / "weights" / src),
+                            "--out", str(ref_out), "--precision", prec], check=True, capture_output=True, cwd=str(tmp_path))
+            assert open(out, "rb").read() == open(ref_out, "rb").read(), prec
+    r = subprocess.run([os.path.join(PKG, "yolov2_weight_gen"), "--weights", "/nonexistent.bin", "--cfg", cfg], capture_output=True, text=True)
+    assert r.returncode == 1 and "Fatal error" in r.stderr

@@ -13,8 +13,10 @@
 //   M = real pixels (b,y,x),  N = output channels,  K = taps x Cp  (tap-major, channel-minor)
 //   A[m][k] = act[f(m) + tapoff][c]   (64 contiguous bytes per pixel per 32-channel K-step)
 //   B[k][n] = wh[n][tap][c]           (K-contiguous per output channel)
-// Block = 256 threads = 2x2 wavefronts, tile 128 pixels x 128 channels, K-step 32; each wavefront
-// owns 64x64 = 2x2 MFMA tiles (64 fp32 accumulators per lane).  A and B K-step tiles are staged in
+// Block tile BM pixels x BN channels, one wavefront per 64x64 (2x2 MFMA tiles, 64 fp32 accumulators
+// per lane): 128x128 (4 wavefronts, two workgroups per CU) or 128x64 for <= 64-channel layers;
+// K-step 64 (32 where the item size is 32).  The template also builds 256x128 with 8 wavefronts;
+// measured 8 % slower, so it is not launched.  A and B K-step tiles are staged in
 // LDS (rows padded from 64 to 80 bytes: conflict-free ds_read_b128 fragments), double-buffered,
 // with the global loads of step k+1 in flight while step k is multiplied.
 #pragma once
@@ -40,9 +42,10 @@ struct ConvF16Args {
     int npix;              // B*H*W
     int leaky;
     int KS;                // 1 or 3
+    int n_tiles;           // output-channel tiles per pixel tile (grid = pixel tiles x n_tiles, 1-D)
 };
 
-constexpr int kBM = 128, kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
+constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
 constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
 
 __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
@@ -57,16 +60,19 @@ __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
 // act: items of Cp_in halves (pointer at item 0 incl. lead); wh: [N_pad][KK][Cp_in] halves;
 // bias: [N_pad] fp32; out: items of Cp_out halves; out_f32 (optional): dense [B][N][H][W] fp32.
 // BN = 128: 2x2 wavefronts of 64x64;  BN = 64 (layers with <= 64 output channels): 4x1 of 32x64.
-template <int BN, int BK>
-__global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) * (BN / 64) * 64) void k_conv_f16(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                    const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                    float *__restrict__ out_f32, const ConvF16Args a)
 {
-    constexpr int WN = BN / 64, WM = 4 / WN;   // wavefront grid
+    constexpr int kBM = BM;
+    constexpr int WN = BN / 64;                                     // wavefront grid: WM x WN
+    constexpr int NT = ((BM / 64) * WN * 64 < 256) ? 256 : (BM / 64) * WN * 64;   // threads: 256 or 512
+    constexpr int WM = NT / 64 / WN;
     constexpr int MT = kBM / WM / 32;          // 32-row MFMA tiles per wavefront along M (2 or 1)
     constexpr int kBK = BK, kLdsRow = BK + 8;
     constexpr int CPR = BK / 8;                // 16-byte chunks per staged row (4 or 8)
-    constexpr int RPP = 256 / CPR;             // rows staged per pass of the 256 threads (64 or 32)
+    constexpr int RPP = NT / CPR;              // rows staged per pass of the workgroup
     constexpr int APASS = kBM / RPP, BPASS = BN / RPP;
     // one LDS arena: K-loop staging (A: 2 x 128 x 40, B: 2 x BN x 40 halves), reused by the epilogue
     // as a [128][136] fp16 tile so that the output leaves in 16-byte stores
@@ -80,11 +86,13 @@ __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ a
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int HW = a.H * a.W;
-    const int q0 = blockIdx.x * kBM;
-    const int n0 = blockIdx.y * BN;
+    // 1-D grid, channel tile fastest: the gridDim.y... workgroups that share one pixel tile (the A
+    // operand) are launched back to back, so A is fetched from HBM once and hit in L2 by the rest
+    const int q0 = (blockIdx.x / a.n_tiles) * kBM;
+    const int n0 = (blockIdx.x % a.n_tiles) * BN;
     const int KK = a.KS * a.KS;
 
-    if (tid < kBM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    for (int i = tid; i < kBM; i += NT) fo_s[i] = flat_of_h(min(q0 + i, a.npix - 1), HW, a.W, a.Wp, a.PL);
     __syncthreads();
 
     // staging map: thread -> (row, 16-byte chunk), APASS / BPASS rows per thread
@@ -106,13 +114,16 @@ __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ a
     const int csteps = a.Cp_in / kBK;
     const int nsteps = KK * csteps;
 
-    auto koff = [&](int step, long &aoff, long &boff) {
-        const int tap = step / csteps, c0 = (step - tap * csteps) * kBK;
-        const int toff = (a.KS == 3) ? ((tap / 3 - 1) * a.Wp + (tap % 3 - 1)) : 0;
-        aoff = (long)toff * a.Cp_in + c0;
-        boff = (long)tap * a.Cp_in + c0;
+    // K-step -> (tap, channel chunk); steps are visited in order, so the pair is advanced
+    // incrementally (no integer division in the loop)
+    int k_tap = 0, k_c0 = 0;
+    auto koff = [&](int /*step*/, long &aoff, long &boff) {
+        const int toff = (a.KS == 3) ? ((k_tap / 3 - 1) * a.Wp + (k_tap % 3 - 1)) : 0;
+        aoff = (long)toff * a.Cp_in + k_c0;
+        boff = (long)k_tap * a.Cp_in + k_c0;
+        k_c0 += kBK;
+        if (k_c0 >= a.Cp_in) { k_c0 = 0; ++k_tap; }
     };
-
     half8_t ra[APASS], rb[BPASS];
     auto stage_load = [&](int step) {
         long ao, bo;
@@ -137,21 +148,36 @@ __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ a
         const int cur = step & 1;
         const bool more = step + 1 < nsteps;
         if (more) stage_load(step + 1);  // global loads of the next K-step fly while this one is multiplied
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {
-            half8_t af[MT], bf[2];
+        // fragment reads of sub-step kk+1 are issued before the MFMAs of sub-step kk (register
+        // double buffer), so the matrix pipe does not wait on LDS latency four times per K-step
+        half8_t af[2][MT], bf[2][2];
+        auto read_frags = [&](int kk, int set) {
 #pragma unroll
             for (int t = 0; t < MT; ++t)
-                af[t] = *reinterpret_cast<const half8_t *>(&As[cur][wm * (32 * MT) + t * 32 + frow][kk * 16 + fk]);
+                af[set][t] = *reinterpret_cast<const half8_t *>(&As[cur][wm * (32 * MT) + t * 32 + frow][kk * 16 + fk]);
 #pragma unroll
             for (int t = 0; t < 2; ++t)
-                bf[t] = *reinterpret_cast<const half8_t *>(&Bs[cur][wn * 64 + t * 32 + frow][kk * 16 + fk]);
+                bf[set][t] = *reinterpret_cast<const half8_t *>(&Bs[cur][wn * 64 + t * 32 + frow][kk * 16 + fk]);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
         }
+        // pin the interleave hipcc would otherwise undo: reads(0), then {reads(kk+1), MFMAs(kk)}...
+        // (sched_group_barrier masks: 0x100 = DS read, 0x008 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+#pragma unroll
+        for (int kk = 0; kk + 1 < BK / 16; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
         if (more) stage_write(cur ^ 1);
         __syncthreads();
     }
@@ -196,7 +222,7 @@ __global__ __launch_bounds__(256) void k_conv_f16(const _Float16 *__restrict__ a
     }
     __syncthreads();
     constexpr int CH = BN / 8;               // 16-byte chunks per pixel row
-    constexpr int ROWS_PER_PASS = 256 / CH;  // 16 or 32
+    constexpr int ROWS_PER_PASS = NT / CH;
     const int chunk = tid % CH, r0 = tid / CH;
     const int ch0 = n0 + chunk * 8;
     if (ch0 < a.n_store) {

@@ -1273,13 +1273,17 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             const bool bk64 = a.Cp_in % 64 == 0;   // K-step of 64 channels wherever the item size allows it
             const _Float16 *ip = (const _Float16 *)tin->d;
             if (l.n <= 64) {
-                const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, 64) / 64);
-                if (bk64) hipLaunchKernelGGL((k_conv_f16<64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
-                else hipLaunchKernelGGL((k_conv_f16<64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                a.n_tiles = round_up(l.n, 64) / 64;
+                const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
+                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else hipLaunchKernelGGL((k_conv_f16<128, 64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             } else {
-                const dim3 grid((a.npix + kBM - 1) / kBM, round_up(l.n, kBN) / kBN);
-                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
-                else hipLaunchKernelGGL((k_conv_f16<128, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                a.n_tiles = round_up(l.n, kBN) / kBN;
+                // (a 256x128 tile with 8 wavefronts was measured 8 % SLOWER than 128x128 with two
+                //  workgroups per CU: the K loop is bound by its barrier/LDS cadence, not by operand reuse)
+                const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
+                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else hipLaunchKernelGGL((k_conv_f16<128, 128, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             }
             if (i != 30) cur = &c->h_out[i];
             ord++;
