@@ -156,6 +156,14 @@ int yolo2_hip_run_batch_int16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch
 int yolo2_hip_run_batch_int16_host(yolo2_hip_ctx *ctx, const float *frames, int batch,
                                    int16_t *region, int *final_q);
 
+/* Streaming form for hosts that hold many frames in ordinary (pageable) memory: processes
+ * n_frames in chunks of `batch`, with the H2D copy of chunk k+1, the kernels of chunk k and the
+ * D2H copy of chunk k-1 overlapped on three HIP streams through pinned staging buffers, so the
+ * PCIe-inclusive rate approaches the device-resident rate.  Results are identical to calling
+ * yolo2_hip_run_batch_int16 chunk by chunk (a trailing partial chunk is padded with the last frame). */
+int yolo2_hip_run_frames_int16(yolo2_hip_ctx *ctx, const float *frames, int n_frames, int batch,
+                               int16_t *region, int *final_q);
+
 /* ---- fp16 MFMA path (floating-point form of the same network: a true dense contraction).
  * Weights as yolov2_hls_ps holds them for Precision::FP32 (weights_reorg.bin / bias.bin,
  * yolo2_model.cpp:171-181); converted once to fp16 in a K-contiguous layout on the device.

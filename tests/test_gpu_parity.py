@@ -300,6 +300,21 @@ def test_batch64_properties():
     ctx.close()
 
 
+def test_streaming_entry_equals_batched_and_handles_partial_chunks():
+    """yolo2_hip_run_frames_int16: 11 frames in chunks of 4 (last chunk partial), copies overlapped
+    with compute on separate streams; same bits as the plain batched calls."""
+    model = synth.SynthModel(seed=1)
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(40, 10)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    got, q = ctx.run_frames(frames, batch=4)
+    assert q == 9 and got.shape == (11, 425, 13, 13)
+    assert np.array_equal(got[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    want = np.concatenate([ctx.run_batch_host(frames[i:i + 4])[0] for i in (0, 4)] + [ctx.run_batch_host(frames[8:11])[0]])
+    assert np.array_equal(got, want)
+    ctx.close()
+
+
 def test_context_errors():
     ctx = hipdrv.Yolo2Hip(0)
     with pytest.raises(hipdrv.Yolo2HipError, match="load weights"):

@@ -1331,3 +1331,82 @@ extern "C" int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *c, const float *fram
     (void)hipFree(rd);
     return rc;
 }
+
+// ---------------------------------------------------------------------------- streaming host entry
+
+extern "C" int yolo2_hip_run_frames_int16(yolo2_hip_ctx *c, const float *frames, int n_frames, int batch, int16_t *region,
+                                          int *final_q)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    if (n_frames <= 0 || batch <= 0) return fail(YOLO2_ERROR, "bad frame count / batch");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    if (batch != c->batch) {
+        const int rc = yolo2_hip_set_batch(c, batch);
+        if (rc) return rc;
+    }
+    const size_t fbytes = (size_t)batch * YOLO2_FRAME_ELEMS * sizeof(float), rbytes = (size_t)batch * YOLO2_REGION_ELEMS * sizeof(int16_t);
+    float *hin[2] = {nullptr, nullptr}, *din[2] = {nullptr, nullptr};
+    int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t e_in[2], e_run[2], e_out[2];
+    int rc = YOLO2_SUCCESS;
+    auto cleanup = [&]() {
+        for (int k = 0; k < 2; ++k) {
+            if (hin[k]) (void)hipHostFree(hin[k]);
+            if (hout[k]) (void)hipHostFree(hout[k]);
+            if (din[k]) (void)hipFree(din[k]);
+            if (dout[k]) (void)hipFree(dout[k]);
+        }
+        if (s_in) (void)hipStreamDestroy(s_in);
+        if (s_run) (void)hipStreamDestroy(s_run);
+        if (s_out) (void)hipStreamDestroy(s_out);
+    };
+#define Y2_TRY(expr, code) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(code, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    for (int k = 0; k < 2; ++k) {
+        Y2_TRY(hipHostMalloc((void **)&hin[k], fbytes, hipHostMallocDefault), YOLO2_MMAP_ERROR);
+        Y2_TRY(hipHostMalloc((void **)&hout[k], rbytes, hipHostMallocDefault), YOLO2_MMAP_ERROR);
+        Y2_TRY(hipMalloc((void **)&din[k], fbytes), YOLO2_MMAP_ERROR);
+        Y2_TRY(hipMalloc((void **)&dout[k], rbytes), YOLO2_MMAP_ERROR);
+        Y2_TRY(hipEventCreateWithFlags(&e_in[k], hipEventDisableTiming), YOLO2_ERROR);
+        Y2_TRY(hipEventCreateWithFlags(&e_run[k], hipEventDisableTiming), YOLO2_ERROR);
+        Y2_TRY(hipEventCreateWithFlags(&e_out[k], hipEventDisableTiming), YOLO2_ERROR);
+    }
+    Y2_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), YOLO2_ERROR);
+    Y2_TRY(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), YOLO2_ERROR);
+    Y2_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), YOLO2_ERROR);
+
+    const int chunks = (n_frames + batch - 1) / batch;
+    auto frames_in_chunk = [&](int k) { return std::min(batch, n_frames - k * batch); };
+    auto drain = [&](int k) {   // copy chunk k's results from its pinned buffer to the caller's memory
+        const int b = k & 1;
+        (void)hipEventSynchronize(e_out[b]);
+        memcpy(region + (size_t)k * batch * YOLO2_REGION_ELEMS, hout[b], (size_t)frames_in_chunk(k) * YOLO2_REGION_ELEMS * sizeof(int16_t));
+    };
+    int q = 0;
+    for (int k = 0; k < chunks && rc == YOLO2_SUCCESS; ++k) {
+        const int b = k & 1, nf = frames_in_chunk(k);
+        if (k >= 2) drain(k - 2);   // buffer set b is free again once chunk k-2 has left it
+        // stage: pageable -> pinned (CPU), pad a partial last chunk with its last frame
+        memcpy(hin[b], frames + (size_t)k * batch * YOLO2_FRAME_ELEMS, (size_t)nf * YOLO2_FRAME_ELEMS * sizeof(float));
+        for (int f = nf; f < batch; ++f)
+            memcpy(hin[b] + (size_t)f * YOLO2_FRAME_ELEMS, hin[b] + (size_t)(nf - 1) * YOLO2_FRAME_ELEMS, YOLO2_FRAME_ELEMS * sizeof(float));
+        Y2_TRY(hipMemcpyAsync(din[b], hin[b], fbytes, hipMemcpyHostToDevice, s_in), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(e_in[b], s_in), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(s_run, e_in[b], 0), YOLO2_ERROR);
+        rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)din[b], batch, (uint64_t)(uintptr_t)dout[b], &q, s_run);
+        if (rc) break;
+        Y2_TRY(hipEventRecord(e_run[b], s_run), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(s_out, e_run[b], 0), YOLO2_ERROR);
+        Y2_TRY(hipMemcpyAsync(hout[b], dout[b], rbytes, hipMemcpyDeviceToHost, s_out), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(e_out[b], s_out), YOLO2_ERROR);
+    }
+    if (rc == YOLO2_SUCCESS) {
+        for (int k = std::max(0, chunks - 2); k < chunks; ++k) drain(k);
+        if (final_q) *final_q = q;
+    }
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(e_in[k]); (void)hipEventDestroy(e_run[k]); (void)hipEventDestroy(e_out[k]); }
+    cleanup();
+#undef Y2_TRY
+    return rc;
+}

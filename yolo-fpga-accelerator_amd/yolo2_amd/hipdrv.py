@@ -29,7 +29,7 @@ EXPORTS = [
     "yolo2_hip_debug_layer_output", "yolo2_hip_set_profiling", "yolo2_hip_layer_times_ms",
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
-    "yolo2_hip_layer_path_counts", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
+    "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
 ]
 
 
@@ -72,6 +72,7 @@ def lib():
     L.yolo2_hip_load_weights_int16.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32]
     L.yolo2_hip_load_weights_int16_dev.argtypes = [vp, u64, C.c_size_t, u64, C.c_size_t, vp, i32, vp, i32, vp, i32]
     L.yolo2_hip_layer_path.argtypes = [vp, i32]
+    L.yolo2_hip_run_frames_int16.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.yolo2_hip_layer_path_counts.argtypes = [vp, i32, C.POINTER(i32)]
     L.yolo2_hip_set_batch.argtypes = [vp, i32]
     L.yolo2_hip_run_batch_int16.argtypes = [vp, u64, i32, u64, C.POINTER(i32), vp]
@@ -273,6 +274,16 @@ class Yolo2Hip:
         check(lib().yolo2_hip_run_batch_fp16_host(self._h, frames.ctypes.data_as(C.c_void_p), B,
                                                   region.ctypes.data_as(C.c_void_p)), "yolo2_hip_run_batch_fp16_host")
         return region
+
+    def run_frames(self, frames: np.ndarray, batch: int):
+        """Streaming entry: any number of host frames, chunks of `batch`, copies overlapped with compute."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n = frames.shape[0]
+        region = np.empty((n, 425, 13, 13), dtype=np.int16)
+        q = C.c_int(0)
+        check(lib().yolo2_hip_run_frames_int16(self._h, frames.ctypes.data_as(C.c_void_p), n, batch,
+                                               region.ctypes.data_as(C.c_void_p), C.byref(q)), "yolo2_hip_run_frames_int16")
+        return region, q.value
 
     def debug_layer_output(self, layer_idx: int, frame: int = 0) -> np.ndarray:
         l = net.LAYERS[layer_idx]
