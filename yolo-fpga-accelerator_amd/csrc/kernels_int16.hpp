@@ -159,7 +159,10 @@ __device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
 // MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
 // MODE 3: 32-bit form C (packed int16 accumulators, saturating packed add), 3.5 instructions per step.
 // NST: staging registers per thread, 256*NST >= LDS tile items.
-template <int KS, int P, int MODE, int NST>
+// GRP (1x1 convs only): channel groups staged and consumed per barrier.  A 1x1 conv has one tap per
+//      group, i.e. only 8*P steps between barriers; with GRP = 8 the loop body looks like a 3x3
+//      group (the weight slices of consecutive groups are contiguous, exactly like taps).
+template <int KS, int P, int MODE, int NST, int GRP = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                    const int2 *__restrict__ wpk,
                                                    const short *__restrict__ bias, const ConvArgs a)
@@ -168,7 +171,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     constexpr bool X64 = MODE == 2;
     typedef typename std::conditional<X64, long, int>::type acc_t;
     constexpr int T = 64 * P;
-    constexpr int KK = KS * KS;
+    constexpr int KK = KS * KS * GRP;   // "taps" per barrier: spatial taps, or channel groups for GRP > 1
+    static_assert(GRP == 1 || KS == 1, "grouping is for 1x1 convs");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -234,33 +238,38 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     if (MODE != 2) asm volatile("" : "+v"(r_vgpr));
     const char *lds_b = reinterpret_cast<const char *>(lds);
     const int2 *src = in + kLead + tile_start;
-    const int2 *wq = wpk + ((long)mb * a.CGin * KK * 32 + wave * 8);
+    const int2 *wq = wpk + ((long)mb * a.CGin * (KS * KS) * 32 + wave * 8);   // [mb][cg][tap][32]: KS*KS taps per group
 
     // Input tiles are double-buffered in LDS: the global loads of group cg+1 are issued before the
     // compute on group cg and written to the other buffer after it, so HBM/L2 latency hides behind
     // ~KK*P*8 requant steps and there is ONE barrier per channel group.
     int2 stage[NST];
-    const int buf_items = a.lt_max;
+    const int buf_items = a.lt_max * GRP;
+    // staging index i -> (group g, item j): g = i / Lt for GRP > 1 (one division per staged item, outside the step loop)
+    auto src_off = [&](int i) -> long { if (GRP == 1) return i; const int g = i / Lt; return (long)g * a.in_cg_stride + (i - g * Lt); };
+    auto lds_off = [&](int i) -> int { if (GRP == 1) return i; const int g = i / Lt; return g * a.lt_max + (i - g * Lt); };
+    const int LtG = Lt * GRP;
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = tid + k * 256;
-        if (i < Lt) stage[k] = src[i];
+        if (i < LtG) stage[k] = src[src_off(i)];
     }
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
         const int i = tid + k * 256;
-        if (i < Lt) lds[i] = stage[k];
+        if (i < LtG) lds[lds_off(i)] = stage[k];
     }
     __syncthreads();
 
     int chain = 0;
-    for (int cg = 0; cg < a.CGin; ++cg) {
-        // branch-free: the last group re-fetches its own tile instead of testing `cg + 1 < CGin`
-        src += (cg + 1 < a.CGin) ? a.in_cg_stride : 0;
+    const int niter = a.CGin / GRP;   // the host only selects GRP > 1 when it divides CGin
+    for (int cg = 0; cg < niter; ++cg) {
+        // branch-free: the last group re-fetches its own tile instead of testing `cg + 1 < niter`
+        src += (cg + 1 < niter) ? a.in_cg_stride * GRP : 0;
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + k * 256;
-            if (i < Lt) stage[k] = src[i];
+            if (i < LtG) stage[k] = src[src_off(i)];
         }
         const char *tile = lds_b + (cg & 1) * buf_items * 8;
 #pragma unroll
@@ -270,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                int2 x = *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8);
+                int2 x = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
+                                    : *reinterpret_cast<const int2 *>(tile + tap * a.lt_max * 8 + rowaddr[p][0]);
                 // Form A's dot products do not depend on the accumulators, so hipcc would compute
                 // all 72x8 of a group up front (hundreds of live registers, SGPR spills).  An empty
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 #pragma unroll
             for (int k = 0; k < NST; ++k) {
                 const int i = tid + k * 256;
-                if (i < Lt) nxt[i] = stage[k];
+                if (i < LtG) nxt[lds_off(i)] = stage[k];
             }
         }
         wq += KK * 32;

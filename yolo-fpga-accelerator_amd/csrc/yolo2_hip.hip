@@ -156,6 +156,10 @@ struct ConvPlan {
     int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 2 = 64-bit
     int P = 8;
     int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
+    int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
+    int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
+                               // fewer co-resident workgroups finish sooner each, which shortens the
+                               // idle tail of layers that are only a few workgroup-generations long
     dim3 grid;
     int lds_bytes = 0;
     ConvArgs args;
@@ -191,14 +195,20 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
-    p.lds_bytes = a.lt_max * 8 * 2;  // double-buffered input tile
+    p.grp = (p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
+    p.lds_bytes = std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
 }
 
 template <int KS, int MODE, int P>
 static void launch_conv_n(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
 {
-    const int nst = (p.args.lt_max + 255) / 256;
+    const int nst = (p.args.lt_max * p.grp + 255) / 256;
+    if (KS == 1 && p.grp == 8 && MODE != 2) {
+        if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 4, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        else hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 8, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        return;
+    }
     if (nst <= 2) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
     else if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 4>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
     else hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
@@ -897,9 +907,14 @@ static int autotune(yolo2_hip_ctx *c)
         for (auto &e : c->extra[i]) subs.push_back(&e);
         for (ConvPlan *sp : subs) {
             float best = 1e30f;
-            int bestP = sp->P;
-            for (int P : {8, 4, 2, 1}) {
+            int bestP = sp->P, bestPad = 0;
+            // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap)
+            for (int cfg = 0; cfg < 12; ++cfg) {
+                const int P = 8 >> (cfg & 3);
+                const int pad = (cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4);
+                if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
                 ConvPlan cand = *sp;
+                cand.lds_pad = pad;
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
@@ -912,8 +927,9 @@ static int autotune(yolo2_hip_ctx *c)
                     HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
                     tmin = std::min(tmin, t);
                 }
-                if (tmin < best) { best = tmin; bestP = P; }
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; }
             }
+            sp->lds_pad = bestPad;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
         ord++;
