@@ -236,6 +236,174 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) 
     }
 }
 
+// ---- LDS-DMA variant (K-step 64) -------------------------------------------------------------
+// Ablation of the register-staged kernel above (YOLO2_F16_DBG): of 0.505 ms for a
+// 13x13x512->1024 layer at batch 256, 0.12 ms are the global->VGPR loads and 0.13 ms the
+// ds_write_b128 pass that copies them into LDS; the MFMAs need 0.18 ms.  This variant lets the
+// loads write LDS directly (global_load_lds_dwordx4: no VGPRs, no ds_write): each wave-instruction
+// fills 1 KiB = 8 rows x 128 B of an UNPADDED tile, so bank conflicts are avoided by permuting the
+// 16-byte chunk each lane fetches instead of padding rows:
+//     LDS slot = chunk ^ ((row >> 1) & 7)        (conflict-free for the ds_read_b128 lane groups)
+// applied on the global source address when filling and on the LDS address when reading fragments.
+// All LDS lives in ONE array (a second __shared__ object makes hipcc drain the DMA before every
+// fragment read, cdna_hip_programming.md section 5).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int BN>
+__global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+                                                        const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                        float *__restrict__ out_f32, const ConvF16Args a)
+{
+    constexpr int BM = 128, BK = 64, ROWH = BK;            // halves per (unpadded) LDS row = 128 B
+    constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 32;
+    constexpr int AG = BM / 8 / 4, BG = BN / 8 / 4;        // 8-row groups per wavefront for A and B
+    constexpr int kStageHalves = 2 * BM * ROWH + 2 * BN * ROWH;
+    constexpr int kEpiHalves = BM * kCtRow;
+    constexpr int kArena = kStageHalves > kEpiHalves ? kStageHalves : kEpiHalves;
+    __shared__ __attribute__((aligned(1024))) _Float16 smem[kArena + 2 * BM];   // + fo table (BM ints) at the end
+    int *fo_s = reinterpret_cast<int *>(smem + kArena);
+    _Float16 *As = smem;                       // [2][BM][64]
+    _Float16 *Bs = smem + 2 * BM * ROWH;       // [2][BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int HW = a.H * a.W;
+    const int q0 = (blockIdx.x / a.n_tiles) * BM;
+    const int n0 = (blockIdx.x % a.n_tiles) * BN;
+    const int KK = a.KS * a.KS;
+
+    if (tid < BM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    __syncthreads();
+
+    // fill map: wave-instruction i covers rows R0 = (wave*G + i)*8 .. +7; lane -> (row, LDS slot); source chunk = slot ^ swz(row)
+    const int lrow = lane >> 3, lslot = lane & 7;
+    size_t a_src[AG], b_src[BG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave * AG + i) * 8 + lrow;
+        a_src[i] = ((size_t)kLead + fo_s[row]) * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave * BG + i) * 8 + lrow;
+        b_src[i] = (size_t)(n0 + row) * KK * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+    }
+
+    float16_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nsteps = KK * (a.Cp_in / BK);
+    int k_tap = 0, k_c0 = 0;
+    auto fill = [&](int buf) {   // issue the LDS-DMA loads of the next K-step into buffer `buf`
+        const int toff = (a.KS == 3) ? ((k_tap / 3 - 1) * a.Wp + (k_tap % 3 - 1)) : 0;
+        const long ao = (long)toff * a.Cp_in + k_c0, bo = (long)k_tap * a.Cp_in + k_c0;
+        k_c0 += BK;
+        if (k_c0 >= a.Cp_in) { k_c0 = 0; ++k_tap; }
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(act + a_src[i] + ao),
+                                             (lds_void_t *)(As + ((size_t)buf * BM + (wave * AG + i) * 8) * ROWH), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(wh + b_src[i] + bo),
+                                             (lds_void_t *)(Bs + ((size_t)buf * BN + (wave * BG + i) * 8) * ROWH), 16, 0, 0);
+    };
+    fill(0);
+    __syncthreads();   // hipcc drains the DMA (vmcnt(0)) ahead of the barrier
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) fill(cur ^ 1);   // lands while this K-step is multiplied
+        half8_t af[2][MT], bf[2][2];
+        auto read_frags = [&](int kk, int set) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int row = wm * (32 * MT) + t * 32 + frow;
+                af[set][t] = *reinterpret_cast<const half8_t *>(As + ((size_t)cur * BM + row) * ROWH + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) * 8));
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = wn * 64 + t * 32 + frow;
+                bf[set][t] = *reinterpret_cast<const half8_t *>(Bs + ((size_t)cur * BN + row) * ROWH + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) * 8));
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+#pragma unroll
+        for (int kk = 0; kk + 1 < BK / 16; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+        __syncthreads();
+    }
+
+    if (out_f32) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (ch >= a.N) continue;
+            const float bv = bias[ch];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const int q = q0 + row;
+                    if (q >= a.npix) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (a.leaky && v < 0.f) v *= 0.1f;
+                    const int b = q / HW, rem = q - b * HW;
+                    out_f32[((size_t)b * a.N + ch) * HW + rem] = v;
+                }
+        }
+        return;
+    }
+    _Float16 (*Ct)[kCtRow] = reinterpret_cast<_Float16 (*)[kCtRow]>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        const float bv = bias[n0 + col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r] + bv;
+                if (a.leaky && v < 0.f) v *= 0.1f;
+                Ct[row][col] = (_Float16)v;
+            }
+    }
+    __syncthreads();
+    constexpr int CH = BN / 8, ROWS_PER_PASS = 256 / CH;
+    const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
+    if (ch0 < a.n_store) {
+#pragma unroll
+        for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
+            const int row = r0 + rr * ROWS_PER_PASS;
+            if (q0 + row >= a.npix) continue;
+            const half8_t v = *reinterpret_cast<const half8_t *>(&Ct[row][chunk * 8]);
+            *reinterpret_cast<half8_t *>(out + ((size_t)kLead + fo_s[row]) * a.Cp_out + a.out_ch_off + ch0) = v;
+        }
+    }
+}
+
 // Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:
 // K = 27 is too thin for the matrix cores, and the 416x416x32 intermediate is never needed again
 // (yolov2.cfg: layer 1 is its only consumer), so this kernel keeps it in registers.  One lane owns

@@ -1288,17 +1288,20 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             float *of = i == 30 ? (float *)(uintptr_t)region_dev : (float *)nullptr;
             const bool bk64 = a.Cp_in % 64 == 0;   // K-step of 64 channels wherever the item size allows it
             const _Float16 *ip = (const _Float16 *)tin->d;
+            const bool glds = bk64 && !getenv("YOLO2_F16_NO_GLDS");   // LDS-DMA staging wherever the K-step is 64
             if (l.n <= 64) {
                 a.n_tiles = round_up(l.n, 64) / 64;
                 const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
-                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                if (glds) hipLaunchKernelGGL((k_conv_f16_glds<64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else hipLaunchKernelGGL((k_conv_f16<128, 64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             } else {
                 a.n_tiles = round_up(l.n, kBN) / kBN;
                 // (a 256x128 tile with 8 wavefronts was measured 8 % SLOWER than 128x128 with two
                 //  workgroups per CU: the K loop is bound by its barrier/LDS cadence, not by operand reuse)
                 const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
-                if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                if (glds) hipLaunchKernelGGL((k_conv_f16_glds<128>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
+                else if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else hipLaunchKernelGGL((k_conv_f16<128, 128, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             }
             if (i != 30) cur = &c->h_out[i];
