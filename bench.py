@@ -48,49 +48,56 @@ def conv_layer_bytes(l, batch):
     return act + wts
 
 
-def cpu_baseline(model, frame, gpu_region):
-    """Times the CPU side on a bounded sample (ONE frame) and checks the GPU result against it.
+def _ref_forward_one(orclib, model, frame):
+    """One frame through the reference's own YOLO2_FPGA (oracle/_ref), layer by layer exactly as
+    yolov2_hls_ps drives it (yolo2_model.cpp:294-425), std Q set."""
+    x = np.zeros((3, 416, 416), dtype=np.int16)
+    orclib.oracle().orc_quantize_input(np.ascontiguousarray(frame), x.reshape(-1), x.size, int(model.act_q[0]))
+    wq, bq, aq = model.weight_q, model.bias_q, model.act_q
+    outs = {}
+    cur = x
+    for l in net.LAYERS:
+        if l.type == net.CONV:
+            src = outs[16] if l.idx == 26 else (np.concatenate([outs[27], outs[24]]) if l.idx == 29 else cur)
+            cur = orclib.ref_conv(src, model.w_reorg[l.ord], model.bias[l.ord], l.c, l.n, l.size, 1, l.w, l.h,
+                                  l.pad, l.leaky, int(wq[l.ord]), int(aq[l.ord]), int(aq[l.ord + 1]), int(bq[l.ord]))
+            outs[l.idx] = cur
+        elif l.type == net.MAXPOOL:
+            cur = orclib.ref_maxpool(cur, l.c, l.w, l.h)
+            outs[l.idx] = cur
+        elif l.type == net.REORG:
+            o = np.zeros((256, 13, 16), dtype=np.int16)
+            orclib.oracle().orc_reorg_i16(np.ascontiguousarray(cur), o, 0)   # std Q set: no alignment shift
+            cur = o
+            outs[l.idx] = cur
+    return cur[:, :, :13].reshape(-1)
+
+
+def cpu_baseline(model, frames, gpu_regions):
+    """Times the CPU side on a bounded sample (TWO frames, ~13 s) and checks the GPU result against it.
     Preferred: the reference itself, compiled from its own sources (oracle/_ref), driving every
     conv and maxpool layer through its YOLO2_FPGA exactly as yolov2_hls_ps does, single thread
     (the reference is not re-entrant).  Fallback: our C restatement (oracle/liboracle.so)."""
     import orclib
-    out = {}
+    n = len(frames)
     if orclib.have_ref():
-        x = np.zeros((3, 416, 416), dtype=np.int16)
-        orclib.oracle().orc_quantize_input(np.ascontiguousarray(frame), x.reshape(-1), x.size, int(model.act_q[0]))
-        wq, bq, aq = model.weight_q, model.bias_q, model.act_q
-        outs = {}
-        cur = x
         t0 = time.perf_counter()
-        for l in net.LAYERS:
-            if l.type == net.CONV:
-                src = outs[16] if l.idx == 26 else (np.concatenate([outs[27], outs[24]]) if l.idx == 29 else cur)
-                cur = orclib.ref_conv(src, model.w_reorg[l.ord], model.bias[l.ord], l.c, l.n, l.size, 1, l.w, l.h,
-                                      l.pad, l.leaky, int(wq[l.ord]), int(aq[l.ord]), int(aq[l.ord + 1]), int(bq[l.ord]))
-                outs[l.idx] = cur
-            elif l.type == net.MAXPOOL:
-                cur = orclib.ref_maxpool(cur, l.c, l.w, l.h)
-                outs[l.idx] = cur
-            elif l.type == net.REORG:
-                o = np.zeros((256, 13, 16), dtype=np.int16)
-                orclib.oracle().orc_reorg_i16(np.ascontiguousarray(cur), o, 0)   # std Q set: no alignment shift
-                cur = o
-                outs[l.idx] = cur
+        regions = [_ref_forward_one(orclib, model, f) for f in frames]
         dt = time.perf_counter() - t0
-        region = cur[:, :, :13].reshape(-1)
-        out = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
-               "sample": "1 frame: 23 conv + 5 maxpool layers through the reference's own YOLO2_FPGA "
+        out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": f"{n} frames: 23 conv + 5 maxpool layers each through the reference's own YOLO2_FPGA "
                          "(oracle/_ref, built from the reference sources), single thread, weights in memory",
-               "seconds_per_frame": dt}
+               "seconds_per_frame": dt / n}
     else:
         orclib.oracle().orc_set_threads(1)
         t0 = time.perf_counter()
-        region, _, _ = orclib.forward_i16(model, frame)
+        regions = [orclib.forward_i16(model, f)[0] for f in frames]
         dt = time.perf_counter() - t0
-        out = {"value": 1.0 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": "1 frame through oracle/yolo2_oracle.c (bit-exact C restatement), single thread",
-               "seconds_per_frame": dt}
-    out["gpu_matches_cpu_bit_exact"] = bool(np.array_equal(np.asarray(region).reshape(-1), gpu_region.reshape(-1)))
+        out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": f"{n} frames through oracle/yolo2_oracle.c (bit-exact C restatement), single thread",
+               "seconds_per_frame": dt / n}
+    out["gpu_matches_cpu_bit_exact"] = bool(all(np.array_equal(np.asarray(r).reshape(-1), g.reshape(-1))
+                                                for r, g in zip(regions, gpu_regions)))
     return out
 
 
@@ -240,6 +247,8 @@ def main():
     if rank == 0:
         fps = world * B * args.steps / dt
         paths = ctx.layer_paths()
+        lanes = ctx.num_lanes()          # 2: every layer is two concurrent half-batch launches
+        Bl = B // lanes                  # frames per launch
         # dominant kernel = the conv kernel instantiation with the largest total time
         groups = {}
         for l in net.CONVS:
@@ -248,23 +257,33 @@ def main():
             g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "bytes": 0.0, "steps": 0, "layers": []})
             g["ms"] += float(layer_ms[l.idx])
             g["launches"] += 1
-            g["bytes"] += conv_layer_bytes(l, B)
-            g["steps"] += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B
+            g["bytes"] += conv_layer_bytes(l, Bl)
+            g["steps"] += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * Bl
             g["layers"].append(l.idx)
         key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = g["ms"] / g["launches"]
         ach = (g["bytes"] / g["launches"]) / (avg_ms * 1e-3) / 1e9
         kname = f"k_conv_i16<KS={key[0]},P={key[1]},MODE={key[2]}>"
         conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
-        cyc = CYCLES_PER_STEP.get(key[2])
+        # VALU issue roofline over the whole step (chip level, independent of how launches overlap):
+        # SIMD issue cycles the conv steps of one batch need at the measured instruction costs
+        # / cycles available in ms_per_step on 1024 SIMDs at the 2.4 GHz maximum clock
+        need = 0.0
+        for l in net.CONVS:
+            c = CYCLES_PER_STEP.get(paths[l.ord])
+            if c is None:
+                need = None
+                break
+            need += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B / 64 * c
         valu = None
-        if cyc:
-            used = g["steps"] / 64 * cyc / (g["ms"] * 1e-3) / 1e12
-            valu = {"bound": "valu_issue", "kernel": kname, "achieved": used, "peak": VALU_PEAK_TCYCLES,
-                    "unit": "T SIMD issue cycles/s", "frac": used / VALU_PEAK_TCYCLES,
-                    "note": f"{cyc} SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs) at the "
-                            "measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz.  The int16 path is "
-                            "integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
+        if need is not None:
+            used = need / (dt / args.steps) / 1e12
+            valu = {"bound": "valu_issue", "scope": "all conv layers of one step / wall time of the step",
+                    "achieved": used, "peak": VALU_PEAK_TCYCLES, "unit": "T SIMD issue cycles/s",
+                    "frac": used / VALU_PEAK_TCYCLES,
+                    "note": "SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs): form C 14, "
+                            "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
+                            "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
         result = {
             "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -272,7 +291,8 @@ def main():
             "vs_baseline": None, "dtype": "int16", "data": "synthetic",
             "config": {"workload": f"YOLOv2 INT16 416x416 batch={B} per GPU, bit-exact int16 conv/bias/leaky/maxpool/reorg path",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded x{world}, weights broadcast once",
-                       "conv_paths": paths, "conv_path_block_counts": ctx.layer_path_counts()},
+                       "conv_paths": paths, "conv_path_block_counts": ctx.layer_path_counts(),
+                       "lanes": lanes, "frames_per_launch": Bl},
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": None,
@@ -282,8 +302,9 @@ def main():
             "conv_ms_per_step": conv_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            gpu_region0 = region[0].cpu().numpy()
-            result["cpu_baseline"] = cpu_baseline(model, frames[0].cpu().numpy(), gpu_region0)
+            idx = [0, B - 1]    # one frame of each lane
+            result["cpu_baseline"] = cpu_baseline(model, [frames[i].cpu().numpy() for i in idx],
+                                                  [region[i].cpu().numpy() for i in idx])
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

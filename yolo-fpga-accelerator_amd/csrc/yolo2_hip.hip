@@ -578,6 +578,14 @@ struct yolo2_hip_ctx {
     std::vector<ConvPlan> extra[32];   // further launches for blocks that need another arithmetic form
     std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV];
     int *mb_lists = nullptr;           // device: block index lists of all split layers
+    // Lanes: a batch is run as two half-batches on two internal streams (forked from / joined to the
+    // caller's stream with events).  Every layer is then two concurrent launches, and the idle tail of
+    // one (a layer is only a few workgroup-generations long at batch 64) is filled by the other:
+    // +4 % frames/s at batch 64.  A lane is a child context that shares the parent's weights.
+    std::vector<yolo2_hip_ctx *> lanes;
+    bool is_lane = false, laned = false;
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int path_counts[YOLO2_N_CONV][4];
     int reorg_shift = 0, final_q = 0;
     int batch = 0;
@@ -642,12 +650,27 @@ static void free_f16_activations(yolo2_hip_ctx *c)
     c->f16_batch = 0;
 }
 
+static void destroy_lanes(yolo2_hip_ctx *c)
+{
+    for (yolo2_hip_ctx *l : c->lanes) yolo2_hip_destroy(l);
+    c->lanes.clear();
+    c->laned = false;
+}
+
 extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    destroy_lanes(c);
     free_activations(c);
+    if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->is_lane) {   // packed weights and biases belong to the parent
+        c->wpk = nullptr;
+        c->bias_pk = nullptr;
+    }
     free_f16_activations(c);
     if (c->wh) (void)hipFree(c->wh);
     if (c->biasf) (void)hipFree(c->biasf);
@@ -740,6 +763,7 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
     if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias blob too small (%zu < %d)", n_bias, YOLO2_N_BIAS);
     if (n_wq < YOLO2_N_CONV || n_bq < YOLO2_N_CONV) return fail(YOLO2_ERROR, "Q tables too small for conv layers");
     if (n_aq < 1) return fail(YOLO2_ERROR, "Activation Q table (iofm_Q.bin) is required for int16 inference.");
+    destroy_lanes(c);   // they alias the weight buffers that are about to be replaced
     c->weight_q.assign(weight_q, weight_q + n_wq);
     c->bias_q.assign(bias_q, bias_q + n_bq);
     c->act_q.assign(act_q, act_q + n_aq);
@@ -940,12 +964,68 @@ static int autotune(yolo2_hip_ctx *c)
     return YOLO2_SUCCESS;
 }
 
+static int set_batch_single(yolo2_hip_ctx *c, int batch);
+
+static int make_lane(yolo2_hip_ctx *p, yolo2_hip_ctx **out)
+{
+    yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
+    if (!l) return fail(YOLO2_ERROR, "out of host memory");
+    l->device = p->device;
+    l->is_lane = true;
+    l->wpk = p->wpk;
+    l->bias_pk = p->bias_pk;
+    memcpy(l->wpk_off, p->wpk_off, sizeof(p->wpk_off));
+    memcpy(l->bias_off, p->bias_off, sizeof(p->bias_off));
+    memcpy(l->maxsum, p->maxsum, sizeof(p->maxsum));
+    memcpy(l->maxbias, p->maxbias, sizeof(p->maxbias));
+    for (int o = 0; o < YOLO2_N_CONV; ++o) {
+        l->maxsum_mb[o] = p->maxsum_mb[o];
+        l->maxbias_mb[o] = p->maxbias_mb[o];
+    }
+    l->weight_q = p->weight_q;
+    l->bias_q = p->bias_q;
+    l->act_q = p->act_q;
+    int rc = resolve_q(l);
+    if (rc == YOLO2_SUCCESS && hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(YOLO2_ERROR, "hipStreamCreate failed");
+    if (rc == YOLO2_SUCCESS && hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess) rc = fail(YOLO2_ERROR, "hipEventCreate failed");
+    if (rc) { yolo2_hip_destroy(l); return rc; }
+    l->weights_loaded = true;
+    *out = l;
+    return YOLO2_SUCCESS;
+}
+
 extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
 {
     if (!c) return fail(YOLO2_ERROR, "null ctx");
     if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
     if (!c->weights_loaded) return fail(YOLO2_ERROR, "load weights before set_batch");
     HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    const bool want_lanes = !c->is_lane && batch >= 16 && batch % 2 == 0 && !getenv("YOLO2_NO_LANES");
+    if (!want_lanes) {
+        destroy_lanes(c);
+        return set_batch_single(c, batch);
+    }
+    if (c->laned && c->batch == batch) return YOLO2_SUCCESS;
+    destroy_lanes(c);
+    free_activations(c);
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
+    for (int i = 0; i < 2; ++i) {
+        yolo2_hip_ctx *l = nullptr;
+        int rc = make_lane(c, &l);
+        if (rc == YOLO2_SUCCESS) {
+            c->lanes.push_back(l);
+            rc = set_batch_single(l, batch / 2);
+        }
+        if (rc) { destroy_lanes(c); return rc; }
+    }
+    if (c->prof) (void)yolo2_hip_set_profiling(c->lanes[0], 1);
+    c->batch = batch;
+    c->laned = true;
+    return YOLO2_SUCCESS;
+}
+
+static int set_batch_single(yolo2_hip_ctx *c, int batch)
+{
     if (c->batch != batch) {
         free_activations(c);
         int rc;
@@ -990,9 +1070,15 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     return YOLO2_SUCCESS;
 }
 
+extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? 2 : 1; }
+
 extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
 {
     if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (c->laned) {   // with lanes the events of lane 0 are reported (its launches overlap lane 1's)
+        c->prof = enable != 0;
+        return yolo2_hip_set_profiling(c->lanes[0], enable);
+    }
     if (enable && !c->ev_made) {
         for (auto &slot : c->ev)
             for (auto &e : slot) HIP_TRY(hipEventCreate(&e), YOLO2_ERROR);
@@ -1006,6 +1092,7 @@ extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
 extern "C" int yolo2_hip_layer_times_ms(yolo2_hip_ctx *c, float *ms32)
 {
     if (!c || !ms32) return fail(YOLO2_ERROR, "null argument");
+    if (c->laned) return yolo2_hip_layer_times_ms(c->lanes[0], ms32);
     if (c->prof_runs == 0) return fail(YOLO2_ERROR, "no profiled run yet");
     const int n = (int)std::min<long>(c->prof_runs, yolo2_hip_ctx::kProfSlots);
     for (int i = 0; i < 32; ++i) ms32[i] = 0.f;
@@ -1024,6 +1111,7 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
                                           int *ppl)
 {
     if (!c || !c->batch) return fail(YOLO2_ERROR, "set_batch first");
+    if (c->laned) return yolo2_hip_conv_launch_info(c->lanes[0], ord, grid_x, grid_y, block, lds_bytes, ppl);
     int o = 0;
     for (int i = 0; i < 32; ++i)
         if (kNet[i].type == L_CONV) {
@@ -1051,6 +1139,22 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
         if (rc) return rc;
     }
     hipStream_t st = (hipStream_t)stream;
+    if (c->laned) {   // fork the two half-batches onto the lane streams, join back into the caller's stream
+        const int half = batch / 2;
+        HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
+        for (int i = 0; i < 2; ++i) {
+            yolo2_hip_ctx *l = c->lanes[i];
+            HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
+            const int rc = yolo2_hip_run_batch_int16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
+                                                     region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(int16_t), final_q,
+                                                     l->lane_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
+            HIP_TRY(hipStreamWaitEvent(st, l->ev_join, 0), YOLO2_ERROR);
+        }
+        c->final_q = c->lanes[0]->final_q;
+        return YOLO2_SUCCESS;
+    }
     const float *frames = (const float *)(uintptr_t)frames_dev;
     short *region = (short *)(uintptr_t)region_dev;
     const int B = batch;
@@ -1135,6 +1239,10 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
 {
     if (!c || !out) return fail(YOLO2_ERROR, "null argument");
     if (layer_idx < 0 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
+    if (c->laned) {
+        const int half = c->batch / 2;
+        return yolo2_hip_debug_layer_output(c->lanes[frame / half], layer_idx, frame % half, out, cap, out_elems);
+    }
     const LayerDesc &l = kNet[layer_idx];
     if (l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
     const Tensor &t = c->t_out[layer_idx];

@@ -29,7 +29,7 @@ EXPORTS = [
     "yolo2_hip_debug_layer_output", "yolo2_hip_set_profiling", "yolo2_hip_layer_times_ms",
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
-    "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
+    "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
 ]
 
 
@@ -72,6 +72,7 @@ def lib():
     L.yolo2_hip_load_weights_int16.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32]
     L.yolo2_hip_load_weights_int16_dev.argtypes = [vp, u64, C.c_size_t, u64, C.c_size_t, vp, i32, vp, i32, vp, i32]
     L.yolo2_hip_layer_path.argtypes = [vp, i32]
+    L.yolo2_hip_num_lanes.argtypes = [vp]
     L.yolo2_hip_run_frames_int16.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.yolo2_hip_layer_path_counts.argtypes = [vp, i32, C.POINTER(i32)]
     L.yolo2_hip_set_batch.argtypes = [vp, i32]
@@ -294,6 +295,9 @@ class Yolo2Hip:
                                                  out.size, C.byref(n)), "yolo2_hip_debug_layer_output")
         assert n.value == out.size
         return out
+
+    def num_lanes(self) -> int:
+        return lib().yolo2_hip_num_lanes(self._h)
 
     def set_profiling(self, on: bool):
         check(lib().yolo2_hip_set_profiling(self._h, int(on)), "yolo2_hip_set_profiling")
