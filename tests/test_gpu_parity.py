@@ -235,6 +235,48 @@ def test_fullnet_every_tile_shape_and_form(P, path, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("path", [None, "0"])
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_split_k(qset, path, monkeypatch):
+    """The small-batch kernel (16 pixels x 4 K-splits per wavefront, clamp-affine triples combined
+    with wavefront shuffles) forced wherever its bounds hold: the saturating chain split four ways
+    must still be bit-exact against the reference fixture, for 1 and 3 frames (tiles straddling
+    frames) and both Q sets."""
+    monkeypatch.setenv("YOLO2_SPLITK", "1")
+    if path is not None:
+        monkeypatch.setenv("YOLO2_FORCE_PATH", path)   # single-form layers: split-K eligible everywhere legal
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 1, 1), synth.frames(fseed, 1)])
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    for batch in (1, 3):
+        ctx.set_batch(batch)
+        split = [o for o in range(23) if ctx.conv_launch_info(o)["pixels_per_lane"] == 0]
+        if path == "0":
+            # every conv with >= 64 input channels at <= 52x52 (ordinals 6..22 except none) qualifies
+            assert len(split) >= 15, split
+        region, _ = ctx.run_batch_host(frames[:batch])
+        if not np.array_equal(region[0], want):
+            pytest.fail(f"batch {batch} split layers {split}: " + _diagnose(ctx, model, frames[0], 0))
+        if batch == 3:
+            assert np.array_equal(region[2], want) and not np.array_equal(region[1], want)
+    ctx.close()
+
+
+def test_split_k_disabled_by_env(monkeypatch):
+    monkeypatch.setenv("YOLO2_SPLITK", "0")
+    model = synth.SynthModel(seed=1)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    ctx.set_batch(1)
+    assert all(ctx.conv_launch_info(o)["pixels_per_lane"] > 0 for o in range(23))
+    region, _ = ctx.run_batch_host(synth.frames(7, 1))
+    assert np.array_equal(region[0], FULL["i16/std/region_raw_i16"].reshape(425, 13, 13))
+    ctx.close()
+
+
 def test_extreme_weights_select_wide_path():
     """A weight set that can overflow int32 must be routed to the 64-bit kernel by the loader."""
     model = synth.SynthModel(seed=1)

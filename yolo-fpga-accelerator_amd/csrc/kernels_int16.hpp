@@ -343,6 +343,150 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     }
 }
 
+// ------------------------------------------------------------------ split-K variant (small batches)
+//
+// With one frame, a 13x13 layer has 169 pixels: the tiled kernel above leaves most SIMDs idle and
+// every output is a serial chain of CGin*KK saturating steps (up to 2880).  The chain can still be
+// split bit-exactly: each step is the map x -> clamp(x + t, -32768, 32767), and such clamp-affine
+// maps  f(x) = clamp(x + a, l, h)  are closed under composition:
+//     (f2 o f1)(x) = clamp(x + a1 + a2, clamp(l1 + a2, l2, h2), clamp(h1 + a2, l2, h2)).
+// A wavefront here is 16 pixels x 4 K-splits (lane = split*16 + pixel): split s runs channel groups
+// [s*CGin/4, (s+1)*CGin/4) and carries the triple (a, l, h) of its sub-chain per output channel
+// instead of a value; at the end the four triples are combined IN ORDER with two rounds of
+// wavefront shuffles (__shfl_down 16, then 32) and applied to the shifted bias.  Because the splits
+// use different channel groups, the weights are lane-dependent: the four 32-channel weight slices
+// are staged through LDS next to the four input tiles and read into VGPRs.
+// Legal when the host proved |t| < 2^29 and no int32 overflow (form A bound); CGin % 4 == 0.
+constexpr int kSplitBig = 1 << 29;
+
+template <int KS, int NST>
+__global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict__ in, int2 *__restrict__ out,
+                                                          const int2 *__restrict__ wpk,
+                                                          const short *__restrict__ bias, const ConvArgs a)
+{
+    extern __shared__ int2 lds[];
+    constexpr int KK = KS * KS, WITEMS = KK * 32, S = 4, T = 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = lane >> 4, pix = lane & 15;
+    const int mb = a.mb_list ? a.mb_list[blockIdx.y] : (int)blockIdx.y;
+    const int HW = a.H * a.W;
+    const int q0 = blockIdx.x * T;
+    const int qlast = min(q0 + T, a.npix) - 1;
+    const int halo = (KS == 3) ? a.Wp + 1 : 0;
+    const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
+    const int tile_start = fmin - halo;
+    const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
+    const int q = min(q0 + pix, qlast);
+    const bool valid = (q0 + pix <= qlast) && split == 0;   // split-0 lanes hold the combined result
+    const int fo = flat_of(q, HW, a.W, a.Wp, a.PL);
+    const int lo = fo - tile_start;
+    const int Q = a.CGin / S;                               // channel groups per split
+    // one LDS buffer = S input tiles (lt_max items each) followed by S weight slices (WITEMS each)
+    const int buf_items = S * (a.lt_max + WITEMS);
+    int rowaddr[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) rowaddr[i] = (split * a.lt_max + ((KS == 3) ? (lo + (i - 1) * a.Wp - 1) : lo)) * 8;
+    const int waddr = (S * a.lt_max + split * WITEMS + wave * 8) * 8;   // this lane's weight slice, tap 0
+
+    int ta[8], tl[8], th[8];   // the clamp-affine triple of this lane's sub-chain, per output channel
+#pragma unroll
+    for (int m = 0; m < 8; ++m) { ta[m] = 0; tl[m] = -kSplitBig; th[m] = kSplitBig; }
+
+    const int r = a.round, s = a.shift;
+    const int LtS = Lt * S, WS = WITEMS * S, total = LtS + WS;
+    // staging item i: i < LtS -> input tile (split g = i / Lt), else weight slice (split g = (i-LtS) / WITEMS)
+    const int2 *xsrc = in + kLead + tile_start;                               // group 0 of split 0
+    const int2 *wsrc = wpk + (long)mb * a.CGin * KK * 32;                     // this block's 32 channels, group 0
+    // the (split, item) decomposition of a staging index does not depend on the iteration: resolve it
+    // once per thread (pointer at iteration 0, LDS slot, per-iteration stride)
+    const int2 *p0[NST];
+    int slot[NST];
+    long pstep[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        p0[k] = xsrc; slot[k] = 0; pstep[k] = 0;
+        if (i < LtS) {
+            const int g = i / Lt, j = i - g * Lt;
+            p0[k] = xsrc + (long)g * Q * a.in_cg_stride + j;
+            pstep[k] = a.in_cg_stride;
+            slot[k] = g * a.lt_max + j;
+        } else if (i < total) {
+            const int jj = i - LtS, g = jj / WITEMS, j = jj - g * WITEMS;
+            p0[k] = wsrc + (long)g * Q * WITEMS + j;
+            pstep[k] = WITEMS;
+            slot[k] = S * a.lt_max + jj;
+        }
+    }
+    int2 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) stage[k] = p0[k][0]; }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) lds[slot[k]] = stage[k]; }
+    __syncthreads();
+
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    for (int it = 0; it < Q; ++it) {
+        const int itn = (it + 1 < Q) ? it + 1 : it;   // branch-free: the last iteration re-fetches itself
+#pragma unroll
+        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) stage[k] = p0[k][(long)itn * pstep[k]]; }
+        const char *buf = lds_b + (size_t)(it & 1) * buf_items * 8;
+#pragma unroll
+        for (int tap = 0; tap < KK; ++tap) {
+            const int2 x = *reinterpret_cast<const int2 *>(buf + rowaddr[tap / KS] + (tap % KS) * 8);
+            int2 w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
+                d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
+                const int t = d >> s;
+                ta[m] += t;
+                tl[m] = clamp16(tl[m] + t);
+                th[m] = clamp16(th[m] + t);
+            }
+        }
+        int2 *nxt = lds + (size_t)((it + 1) & 1) * buf_items;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) nxt[slot[k]] = stage[k]; }
+        __syncthreads();
+    }
+
+    // ordered combine across the four splits with wavefront shuffles: (s0,s1) and (s2,s3), then both halves
+#pragma unroll
+    for (int delta = 16; delta <= 32; delta <<= 1) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int a2 = __shfl_down(ta[m], delta), l2 = __shfl_down(tl[m], delta), h2 = __shfl_down(th[m], delta);
+            // this lane's map runs first, the partner's (higher split) second: f = f2 o f1
+            tl[m] = min(max(tl[m] + a2, l2), h2);
+            th[m] = min(max(th[m] + a2, l2), h2);
+            ta[m] += a2;
+        }
+    }
+    // apply to the shifted (unsaturated) bias, integer leaky, store 2 items (8 channels) per pixel
+    const short *bp = bias + mb * 32 + wave * 8;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int cgo = mb * 8 + wave * 2 + g;
+        int v[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int m = g * 4 + t;
+            const int b = bp[m];
+            const int b0 = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
+            int e = min(max(b0 + ta[m], tl[m]), th[m]);
+            v[t] = a.leaky ? leaky_i16(e) : e;
+        }
+        int2 o;
+        o.x = (v[0] & 0xffff) | (v[1] << 16);
+        o.y = (v[2] & 0xffff) | (v[3] << 16);
+        if (valid && cgo < a.CGout) out[a.out_base + (long)cgo * a.out_cg_stride + fo] = o;
+    }
+}
+
 // ------------------------------------------------------------------ small kernels
 
 // float [B][3][416][416] -> quantised items (C=3, 4th lane 0).  yolo2_model.cpp:257-273.

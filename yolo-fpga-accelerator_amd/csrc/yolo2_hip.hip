@@ -156,6 +156,8 @@ struct ConvPlan {
     int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 2 = 64-bit
     int P = 8;
     int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
+    int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
+    int splitk = 0;            // small batches: 16 pixels x 4 K-splits per wavefront, shuffle-combined (k_conv_i16_splitk)
     int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
     int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
                                // fewer co-resident workgroups finish sooner each, which shortens the
@@ -179,7 +181,12 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     }
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
-    const int T = 64 * p.P;
+    if (p.splitk) {
+        const int lt = tile_items_bound(gin, 16, halo);
+        if (gin.CG % 4 != 0 || gin.CG < 16 || 4 * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
+    }
+    if (p.splitk) p.P = 1;
+    const int T = p.splitk ? 16 : 64 * p.P;
     ConvArgs &a = p.args;
     // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
     a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
@@ -195,8 +202,8 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
-    p.grp = (p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
-    p.lds_bytes = std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
+    p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
+    p.lds_bytes = p.splitk ? 4 * (a.lt_max + p.K * p.K * 32) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
 }
 
@@ -228,6 +235,13 @@ static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const in
 
 static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
 {
+    if (p.splitk) {
+        const int nst = (4 * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
+        if (p.K == 3) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        else if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_splitk<1, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        else hipLaunchKernelGGL((k_conv_i16_splitk<1, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        return;
+    }
     if (p.K == 3) {
         if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
         else if (p.path == 3) launch_conv_p<3, 3>(p, in, out, wpk, bias, st);
@@ -717,6 +731,15 @@ static int resolve_q(yolo2_hip_ctx *c)
             p.args.mb_list = nullptr;
             p.mb_count = 0;
             p.path = dom;
+            {   // split-K bounds with the layer-wide maxima: form A arithmetic (no int32 overflow), every
+                // increment below 2^29 and the unclamped sum of one split below 2^30
+                const ShiftSpec o = make_shift(so);
+                const long long rnd = o.mag > 0 ? (1LL << (o.mag - 1)) : 0;
+                const long long tmax = so >= 0 ? (((long long)c->maxsum[ord] * 32768 + rnd) >> o.mag) : (1LL << 40);
+                const long long steps = (long long)((l.c + 3) / 4 / 4 + 1) * l.size * l.size;
+                const bool okA = choose_path(so, sb, c->maxsum[ord], c->maxbias[ord]) != 2;
+                p.splitk_ok = okA && tmax < (1LL << 29) && tmax * steps < (1LL << 30);
+            }
             if ((int)groups[dom].size() != MB) {
                 p.mb_count = (int)groups[dom].size();
                 p.args.mb_list = (const int *)(uintptr_t)lists.size();   // offset for now, pointer once uploaded
@@ -932,14 +955,27 @@ static int autotune(yolo2_hip_ctx *c)
         for (ConvPlan *sp : subs) {
             float best = 1e30f;
             int bestP = sp->P, bestPad = 0;
-            // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap)
-            for (int cfg = 0; cfg < 12; ++cfg) {
-                const int P = 8 >> (cfg & 3);
-                const int pad = (cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4);
+            int bestSplit = 0;
+            const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
+            // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
+            for (int cfg = 0; cfg < 13; ++cfg) {
+                const int P = cfg == 12 ? 1 : 8 >> (cfg & 3);
+                const int pad = cfg == 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
                 if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
                 ConvPlan cand = *sp;
                 cand.lds_pad = pad;
+                cand.splitk = 0;
+                if (cfg == 12) {
+                    if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
+                    cand.splitk = 1;
+                } else if (fs && atoi(fs) == 1 && sp->splitk_ok && c->extra[i].empty()) {
+                    ConvPlan probe = *sp;
+                    probe.splitk = 1;
+                    plan_conv(probe, tin.g, tout.g.cg_stride, out_base, CGout, 1);
+                    if (probe.splitk) continue;   // forced: skip the ordinary candidates where split-K is available
+                }
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
+                if (cfg == 12 && !cand.splitk) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
@@ -951,9 +987,10 @@ static int autotune(yolo2_hip_ctx *c)
                     HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
                     tmin = std::min(tmin, t);
                 }
-                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; }
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; }
             }
             sp->lds_pad = bestPad;
+            sp->splitk = bestSplit;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
         ord++;
@@ -1120,7 +1157,7 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
                 if (grid_y) *grid_y = c->plan[i].grid.y;
                 if (block) *block = 256;
                 if (lds_bytes) *lds_bytes = c->plan[i].lds_bytes;
-                if (ppl) *ppl = c->plan[i].P;
+                if (ppl) *ppl = c->plan[i].splitk ? 0 : c->plan[i].P;
                 return YOLO2_SUCCESS;
             }
             o++;
