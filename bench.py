@@ -98,7 +98,36 @@ def cpu_baseline(model, frames, gpu_regions):
                "seconds_per_frame": dt / n}
     out["gpu_matches_cpu_bit_exact"] = bool(all(np.array_equal(np.asarray(r).reshape(-1), g.reshape(-1))
                                                 for r, g in zip(regions, gpu_regions)))
+    # the same work on every host core this process may use.  The reference is not
+    # re-entrant (function-local statics), so this leg is the re-entrant C restatement, OpenMP over
+    # output channels + AVX2 rows; bit-compared with the single-thread result above.
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)      # a one-GPU box's CPU share
+    orclib.oracle().orc_set_threads(cores)
+    t0 = time.perf_counter()
+    mt = [orclib.forward_i16(model, f)[0] for f in frames]
+    dt = time.perf_counter() - t0
+    out["all_cores"] = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                        "sample": f"{n} frames through oracle/yolo2_oracle.c, {cores} OpenMP threads",
+                        "matches_single_thread": bool(all(np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1))
+                                                          for a, b in zip(mt, regions)))}
     return out
+
+
+def hbm_traffic_per_launch(ks, batch):
+    """PMC counters cannot be collected from inside this process: tools/traffic.sh runs this same
+    command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 correction on
+    FETCH_SIZE, checked on k_maxpool2's known byte count) and the result is committed under profiles/.
+    Autotune may pick another pixels-per-lane instantiation per run, so the figure is the mean over all
+    launches of the conv kernel with this kernel size (30 of 3x3, 18 of 1x1 per step)."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    try:
+        doc = json.load(open(path))
+        if doc["batch"] != batch:
+            return None, None
+        return doc["kernels"][f"y2::k_conv_i16<KS={ks},...>"]["hbm_bytes_per_launch"], "profiles/r01_hbm_traffic.json (tools/traffic.sh)"
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
@@ -284,6 +313,7 @@ def main():
                     "note": "SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs): form C 14, "
                             "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
                             "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
+        traffic, traffic_src = hbm_traffic_per_launch(key[0], B)
         result = {
             "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,7 +325,7 @@ def main():
                        "lanes": lanes, "frames_per_launch": Bl},
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]},
             "valu_roofline": valu,
             "layer_ms": [round(float(x), 4) for x in layer_ms],

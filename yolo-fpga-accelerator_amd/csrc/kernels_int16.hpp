@@ -40,6 +40,7 @@ struct ConvArgs {
     int bs_right, bs_left, bs_mag;  // bias shift (exact path computes it itself)
     int leaky;
     int lt_max;                // LDS tile capacity in items
+    int xcd_remap;             // 0 = launch order; 1 + log2(Xm): XCDs as an (8/Xm) x Xm grid over (tiles, blocks)
     const int *mb_list;        // optional: blockIdx.y -> output-channel block (a layer whose blocks need
                                // different arithmetic forms is launched once per form); nullptr = identity
 };
@@ -162,6 +163,38 @@ __device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
 // GRP (1x1 convs only): channel groups staged and consumed per barrier.  A 1x1 conv has one tap per
 //      group, i.e. only 8*P steps between barriers; with GRP = 8 the loop body looks like a 3x3
 //      group (the weight slices of consecutive groups are contiguous, exactly like taps).
+// Workgroups are dealt to the 8 XCDs round-robin in linear launch order (x fastest) and every XCD
+// has its own 4 MiB L2.  Re-number them so that the XCDs form an Xt x Xm grid over (tiles, output-
+// channel blocks): XCD (kt, km) owns a contiguous range of tiles and a contiguous range of blocks and
+// walks it tile-major.  Neighbouring tiles (which share halo rows) and the blocks of one tile then
+// meet in one L2, the input crosses the fabric Xm times and the weights Xt times; the host picks
+// the split that minimises that sum (xm_log2).  Launch order in linear id: XCD = id & 7, the slot
+// within the XCD = id >> 3; XCD k receives q + (k < r) workgroups, so the logical sequence (parts in
+// XCD order) is cut at exactly those counts - with uneven parts a few workgroups spill to the
+// neighbouring XCD, which is harmless.
+__device__ inline void xcd_partition(int xm_log2, int &tile, int &yb)
+{
+    const int gx = gridDim.x, gy = gridDim.y, total = gx * gy;
+    const int lin = blockIdx.x + blockIdx.y * gx;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    int L = xcd * q + min(xcd, r) + slot;               // bijection onto [0, total)
+    const int Xm = 1 << xm_log2, Xt = 8 >> xm_log2;
+    const int qt = gx / Xt, rt = gx - qt * Xt, qm = gy / Xm, rm = gy - qm * Xm;
+    tile = 0; yb = 0;
+    for (int k = 0; k < 8; ++k) {
+        const int kt = k >> xm_log2, km = k & (Xm - 1);
+        const int nt = qt + (kt < rt), nm = qm + (km < rm), cnt = nt * nm;
+        if (L < cnt) {
+            const int dt = L / nm;
+            tile = kt * qt + min(kt, rt) + dt;
+            yb = km * qm + min(km, rm) + (L - dt * nm);
+            break;
+        }
+        L -= cnt;
+    }
+}
+
 template <int KS, int P, int MODE, int NST, int GRP = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                    const int2 *__restrict__ wpk,
@@ -176,9 +209,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mb = a.mb_list ? a.mb_list[blockIdx.y] : (int)blockIdx.y;
+    int tile = blockIdx.x, yb = blockIdx.y;
+    if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
+    const int mb = a.mb_list ? a.mb_list[yb] : yb;
     const int HW = a.H * a.W;
-    const int q0 = blockIdx.x * T;
+    const int q0 = tile * T;
     const int qlast = min(q0 + T, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
     const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL);

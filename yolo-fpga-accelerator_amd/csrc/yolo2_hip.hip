@@ -205,6 +205,25 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
     p.lds_bytes = p.splitk ? 4 * (a.lt_max + p.K * p.K * 32) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
+    // XCD grid over (tiles, blocks): bytes crossing the fabric = input x Xm + weights x Xt x G, where
+    // G > 1 only if the blocks one XCD owns do not keep their weights in its 4 MiB L2 (then every
+    // generation of co-resident tiles fetches them again).  See xcd_partition in kernels_int16.hpp.
+    a.xcd_remap = 0;
+    if (!getenv("YOLO2_NO_XCD_REMAP")) {
+        const double in_bytes = (double)gin.B * gin.CG * gin.PL * 8;
+        const double w_mb = (double)gin.CG * p.K * p.K * 32 * 8;
+        const int gy = (int)p.grid.y, gx = (int)p.grid.x;
+        double best = 0;
+        for (int lg = 0; lg < 4; ++lg) {
+            const int Xm = 1 << lg, Xt = 8 >> lg;
+            if (Xm > gy || Xt > gx) continue;
+            const int own = (gy + Xm - 1) / Xm;
+            double G = 1;
+            if (own * w_mb > 3.0e6) G = std::max(1.0, ((double)gx / Xt) / std::max(1, 128 / own));
+            const double cost = in_bytes * Xm + w_mb * gy * Xt * G;
+            if (!a.xcd_remap || cost < best) { best = cost; a.xcd_remap = 1 + lg; }
+        }
+    }
 }
 
 template <int KS, int MODE, int P>
