@@ -202,6 +202,23 @@ int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x, int *grid_y,
                                int *block, int *lds_bytes, int *pixels_per_lane);
 
+/* GPU pre-processing (the step before the path): the reference host's
+ * load_image_stb (bytes / 255.f, src/core/yolo_image.cpp:29-63) + letterbox_image (two-pass bilinear
+ * resize_image onto a 0.5 canvas, src/core/yolo_image.cpp:84-165) as one kernel, float-for-float in
+ * the reference's operation order, so the frame is bit-identical to the host code's.
+ * image_dev: w x h x channels interleaved bytes (channels 1 or 3; 1 is replicated like stb's grey
+ * load); frame_dev: float [3][net_h][net_w].  Asynchronous on `stream`. */
+int yolo2_hip_letterbox_u8(uint64_t image_dev, int w, int h, int channels, uint64_t frame_dev,
+                           int net_w, int net_h, void *stream);
+
+/* Camera-style whole-network entry: n images of arbitrary sizes as HOST bytes -> int16 region
+ * tensors [n][425][13][13] on the host, in chunks of `batch` images.  The bytes (not the 4x larger
+ * float frames) cross PCIe; letterboxing runs on the GPU; upload, kernels and download of
+ * consecutive chunks overlap on three HIP streams.  Synchronous. */
+int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *ctx, const uint8_t *const *images, const int *widths,
+                                 const int *heights, int channels, int n, int batch,
+                                 int16_t *region_host, int *final_q);
+
 /* ------------------------------------------------------------------- tier 3: helpers */
 
 /* The layer table the batched entry implements (config/yolov2.cfg as parsed by

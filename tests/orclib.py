@@ -206,6 +206,8 @@ def host():
         lib.y2h_boxes_nms.argtypes = [_f32p, C.c_int, C.c_int, C.c_float, C.c_float, _f32p, C.c_int]
         lib.y2h_parse_cfg.argtypes = [C.c_char_p, _i32p, _i32p, C.c_int, _f32p, _i32p]
         lib.y2h_load_pnm.argtypes = [C.c_char_p, _i32p, _f32p, C.c_long]
+        lib.y2h_postprocess_batch.argtypes = [C.c_void_p, C.c_int, C.c_int, _i32p, _i32p, C.c_float, C.c_float, C.c_int,
+                                              _f32p, C.c_int, _i32p]
         _host = lib
     return _host
 

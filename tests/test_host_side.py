@@ -119,3 +119,30 @@ def test_own_weight_gen_matches_reference_tool_and_python(tmp_path):
             assert open(out, "rb").read() == open(ref_out, "rb").read(), prec
     r = subprocess.run([os.path.join(PKG, "yolov2_weight_gen"), "--weights", "/nonexistent.bin", "--cfg", cfg], capture_output=True, text=True)
     assert r.returncode == 1 and "Fatal error" in r.stderr
+
+
+@pytest.mark.parametrize("threads", [1, 4])
+def test_postprocess_batch_equals_single_frame_calls(threads):
+    """The threaded batch tail (int16 region tensors -> detections) gives exactly what the
+    single-frame functions (pinned to the reference above) give frame by frame."""
+    H = orclib.host()
+    full = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullnet.npz"))
+    base = full["i16/std/region_raw_i16"].reshape(-1)
+    q = int(full["i16/std/final_q"])
+    rng = np.random.default_rng(3)
+    B = 6
+    region = np.stack([base if f == 0 else np.roll(base, 1009 * f) + rng.integers(-3, 4, base.size) for f in range(B)]).astype(np.int16)
+    ws = np.array([768, 416, 500, 640, 1, 1920], dtype=np.int32)
+    hs = np.array([576, 416, 375, 480, 1, 1080], dtype=np.int32)
+    thresh, nms = 0.3, 0.45
+    rows = np.zeros((B, 845, 85), dtype=np.float32)
+    totals = np.zeros(B, dtype=np.int32)
+    assert H.y2h_postprocess_batch(region.ctypes.data, B, q, ws, hs, thresh, nms, threads, rows, 845, totals) == 0
+    for f in range(B):
+        raw = np.ascontiguousarray(region[f].astype(np.float32) * np.float32(2.0 ** -q))
+        proc = np.empty_like(raw)
+        H.y2h_region_forward(raw, proc)
+        one = np.zeros((845, 85), dtype=np.float32)
+        n = H.y2h_boxes_nms(proc, int(ws[f]), int(hs[f]), thresh, nms, one, 845)
+        assert n == totals[f] and n > 0
+        assert np.array_equal(rows[f, :n].view(np.uint32), one[:n].view(np.uint32))

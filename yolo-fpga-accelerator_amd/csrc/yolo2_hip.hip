@@ -17,6 +17,7 @@
 
 #include "../../include/yolo2_hip.h"
 #include "kernels_f16.hpp"
+#include "kernels_pre.hpp"
 #include "kernels_int16.hpp"
 #include "layout.hpp"
 
@@ -599,7 +600,21 @@ struct Tensor {
     int2 *d = nullptr;
 };
 
+// Staging for the host-buffer entries (run_frames / run_images): two buffer sets and three streams
+// (upload, kernels, download), kept with the context and grown on demand so that a caller streaming
+// chunk after chunk does not pay pinned-memory allocation per call.
+struct PipeBufs {
+    size_t host_in = 0, dev_in = 0;   // capacities in bytes (dev_in: raw image bytes, 0 for float frames)
+    int batch = 0;
+    uint8_t *hin[2] = {nullptr, nullptr}, *dbytes[2] = {nullptr, nullptr};
+    float *din[2] = {nullptr, nullptr};
+    int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t e_in[2] = {nullptr, nullptr}, e_run[2] = {nullptr, nullptr}, e_out[2] = {nullptr, nullptr};
+};
+
 struct yolo2_hip_ctx {
+    PipeBufs pipe;
     int device = 0;
     bool weights_loaded = false;
     short *wpk = nullptr;      // all layers, packed
@@ -690,11 +705,58 @@ static void destroy_lanes(yolo2_hip_ctx *c)
     c->laned = false;
 }
 
+static void pipe_free(PipeBufs &p)
+{
+    for (int k = 0; k < 2; ++k) {
+        if (p.hin[k]) (void)hipHostFree(p.hin[k]);
+        if (p.hout[k]) (void)hipHostFree(p.hout[k]);
+        (void)hipFree(p.dbytes[k]); (void)hipFree(p.din[k]); (void)hipFree(p.dout[k]);
+        if (p.e_in[k]) (void)hipEventDestroy(p.e_in[k]);
+        if (p.e_run[k]) (void)hipEventDestroy(p.e_run[k]);
+        if (p.e_out[k]) (void)hipEventDestroy(p.e_out[k]);
+    }
+    if (p.s_in) (void)hipStreamDestroy(p.s_in);
+    if (p.s_run) (void)hipStreamDestroy(p.s_run);
+    if (p.s_out) (void)hipStreamDestroy(p.s_out);
+    p = PipeBufs();
+}
+
+static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch)
+{
+    if (p.s_in && p.host_in >= host_in && p.dev_in >= dev_in && p.batch >= batch) return YOLO2_SUCCESS;
+    host_in = std::max(host_in, p.host_in);
+    dev_in = std::max(dev_in, p.dev_in);
+    batch = std::max(batch, p.batch);
+    pipe_free(p);
+    const size_t fbytes = (size_t)batch * YOLO2_FRAME_ELEMS * sizeof(float), rbytes = (size_t)batch * YOLO2_REGION_ELEMS * sizeof(int16_t);
+    bool ok = true;
+    for (int k = 0; k < 2 && ok; ++k) {
+        ok = hipHostMalloc((void **)&p.hin[k], host_in, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void **)&p.hout[k], rbytes, hipHostMallocDefault) == hipSuccess &&
+             (dev_in == 0 || hipMalloc((void **)&p.dbytes[k], dev_in) == hipSuccess) &&
+             hipMalloc((void **)&p.din[k], fbytes) == hipSuccess && hipMalloc((void **)&p.dout[k], rbytes) == hipSuccess &&
+             hipEventCreateWithFlags(&p.e_in[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p.e_run[k], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&p.e_out[k], hipEventDisableTiming) == hipSuccess;
+    }
+    ok = ok && hipStreamCreateWithFlags(&p.s_in, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&p.s_run, hipStreamNonBlocking) == hipSuccess &&
+         hipStreamCreateWithFlags(&p.s_out, hipStreamNonBlocking) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        pipe_free(p);
+        return fail(YOLO2_MMAP_ERROR, "staging buffers for %d frames (+%zu bytes) could not be allocated", batch, host_in);
+    }
+    p.host_in = host_in; p.dev_in = dev_in; p.batch = batch;
+    return YOLO2_SUCCESS;
+}
+
 extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    pipe_free(c->pipe);
     destroy_lanes(c);
     free_activations(c);
     if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
@@ -1321,6 +1383,125 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
     return YOLO2_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------- pre-processing
+
+static int letterbox_args(int w, int h, int channels, int net_w, int net_h, LetterboxArgs &a)
+{
+    if (w <= 0 || h <= 0 || net_w <= 1 || net_h <= 1 || (channels != 1 && channels != 3))
+        return fail(YOLO2_ERROR, "letterbox: bad image geometry %dx%dx%d -> %dx%d", w, h, channels, net_w, net_h);
+    if ((long)w * h > (1L << 28)) return fail(YOLO2_ERROR, "letterbox: image too large");
+    a.w = w; a.h = h; a.ch = channels; a.net_w = net_w; a.net_h = net_h;
+    // letterbox_image, src/core/yolo_image.cpp:148-165
+    if (((float)net_w / w) < ((float)net_h / h)) { a.new_w = net_w; a.new_h = (h * net_w) / w; }
+    else { a.new_h = net_h; a.new_w = (w * net_h) / h; }
+    if (a.new_w < 1 || a.new_h < 1) return fail(YOLO2_ERROR, "letterbox: image aspect too extreme (%dx%d)", w, h);
+    a.off_x = (net_w - a.new_w) / 2;
+    a.off_y = (net_h - a.new_h) / 2;
+    // resize_image, src/core/yolo_image.cpp:89-90 (a one-pixel-wide target divides by zero there too;
+    // the value is then never used because its only column takes the c == w-1 branch)
+    a.w_scale = (float)(w - 1) / (a.new_w - 1);
+    a.h_scale = (float)(h - 1) / (a.new_h - 1);
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_letterbox_u8(uint64_t image_dev, int w, int h, int channels, uint64_t frame_dev, int net_w,
+                                      int net_h, void *stream)
+{
+    if (!image_dev || !frame_dev) return fail(YOLO2_ERROR, "null buffer address");
+    LetterboxArgs a;
+    int rc = letterbox_args(w, h, channels, net_w, net_h, a);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_letterbox_u8, dim3(blocks_for((long)3 * net_w * net_h, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)(uintptr_t)image_dev, (float *)(uintptr_t)frame_dev, a);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+// Camera-style entry: n images of arbitrary sizes as host bytes -> region tensors, in chunks of
+// `batch` images.  The bytes (not the 4x larger float frames) cross PCIe; letterboxing runs on the
+// GPU into the chunk's frame buffer.  Same three-stream pipeline as yolo2_hip_run_frames_int16:
+// upload of chunk k+1 (CPU staging copy + DMA) overlaps the kernels of chunk k and the download of k-1.
+extern "C" int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *c, const uint8_t *const *images, const int *widths,
+                                            const int *heights, int channels, int n, int batch, int16_t *region,
+                                            int *final_q)
+{
+    if (!c || !images || !widths || !heights || !region) return fail(YOLO2_ERROR, "null argument");
+    if (n <= 0 || batch <= 0) return fail(YOLO2_ERROR, "bad image count %d / batch %d", n, batch);
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "weights not loaded");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    batch = std::min(batch, n);
+    const int chunks = (n + batch - 1) / batch;
+    auto in_chunk = [&](int k) { return std::min(batch, n - k * batch); };
+    auto padded = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t cap = 0;   // bytes of the largest chunk
+    for (int k = 0; k < chunks; ++k) {
+        size_t sum = 0;
+        for (int i = k * batch; i < k * batch + in_chunk(k); ++i) {
+            LetterboxArgs a;
+            if (!images[i]) return fail(YOLO2_ERROR, "null image %d", i);
+            const int rc = letterbox_args(widths[i], heights[i], channels, 416, 416, a);
+            if (rc) return rc;
+            sum += padded((size_t)widths[i] * heights[i] * channels);
+        }
+        cap = std::max(cap, sum);
+    }
+    if (batch != c->batch) {
+        const int rc = yolo2_hip_set_batch(c, batch);
+        if (rc) return rc;
+    }
+    const size_t rbytes = (size_t)batch * YOLO2_REGION_ELEMS * sizeof(int16_t);
+    int rc = pipe_ensure(c->pipe, cap, cap, batch);
+    if (rc) return rc;
+    PipeBufs &P = c->pipe;
+    uint8_t **hin = P.hin, **dbytes = P.dbytes;
+    float **din = P.din;
+    int16_t **hout = P.hout, **dout = P.dout;
+    hipStream_t s_in = P.s_in, s_run = P.s_run, s_out = P.s_out;
+    hipEvent_t *e_in = P.e_in, *e_run = P.e_run, *e_out = P.e_out;
+    auto cleanup = [&]() { (void)hipDeviceSynchronize(); };
+#define Y2_TRY(expr, code) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(code, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+
+    auto drain = [&](int k) {
+        const int b = k & 1;
+        (void)hipEventSynchronize(e_out[b]);
+        memcpy(region + (size_t)k * batch * YOLO2_REGION_ELEMS, hout[b], (size_t)in_chunk(k) * YOLO2_REGION_ELEMS * sizeof(int16_t));
+    };
+    int q = 0;
+    std::vector<size_t> offs((size_t)batch);
+    for (int k = 0; k < chunks && rc == YOLO2_SUCCESS; ++k) {
+        const int b = k & 1, nf = in_chunk(k), first = k * batch;
+        if (k >= 2) drain(k - 2);   // buffer set b is free again once chunk k-2 has left it
+        size_t off = 0;
+        for (int i = 0; i < nf; ++i) {
+            const size_t bytes = (size_t)widths[first + i] * heights[first + i] * channels;
+            memcpy(hin[b] + off, images[first + i], bytes);
+            offs[(size_t)i] = off;
+            off += padded(bytes);
+        }
+        Y2_TRY(hipMemcpyAsync(dbytes[b], hin[b], off, hipMemcpyHostToDevice, s_in), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(e_in[b], s_in), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(s_run, e_in[b], 0), YOLO2_ERROR);
+        for (int f = 0; f < batch && rc == YOLO2_SUCCESS; ++f) {   // a partial last chunk repeats its last image
+            const int i = std::min(f, nf - 1);
+            rc = yolo2_hip_letterbox_u8((uint64_t)(uintptr_t)(dbytes[b] + offs[(size_t)i]), widths[first + i], heights[first + i],
+                                        channels, (uint64_t)(uintptr_t)(din[b] + (size_t)f * YOLO2_FRAME_ELEMS), 416, 416, s_run);
+        }
+        if (rc == YOLO2_SUCCESS) rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)din[b], batch, (uint64_t)(uintptr_t)dout[b], &q, s_run);
+        if (rc) break;
+        Y2_TRY(hipEventRecord(e_run[b], s_run), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(s_out, e_run[b], 0), YOLO2_ERROR);
+        Y2_TRY(hipMemcpyAsync(hout[b], dout[b], rbytes, hipMemcpyDeviceToHost, s_out), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(e_out[b], s_out), YOLO2_ERROR);
+    }
+    if (rc == YOLO2_SUCCESS) {
+        for (int k = std::max(0, chunks - 2); k < chunks; ++k) drain(k);
+        if (final_q) *final_q = q;
+    }
+    cleanup();
+#undef Y2_TRY
+    return rc;
+}
+
 // ---------------------------------------------------------------------------- fp16 MFMA path
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -1528,35 +1709,16 @@ extern "C" int yolo2_hip_run_frames_int16(yolo2_hip_ctx *c, const float *frames,
         if (rc) return rc;
     }
     const size_t fbytes = (size_t)batch * YOLO2_FRAME_ELEMS * sizeof(float), rbytes = (size_t)batch * YOLO2_REGION_ELEMS * sizeof(int16_t);
-    float *hin[2] = {nullptr, nullptr}, *din[2] = {nullptr, nullptr};
-    int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
-    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
-    hipEvent_t e_in[2], e_run[2], e_out[2];
-    int rc = YOLO2_SUCCESS;
-    auto cleanup = [&]() {
-        for (int k = 0; k < 2; ++k) {
-            if (hin[k]) (void)hipHostFree(hin[k]);
-            if (hout[k]) (void)hipHostFree(hout[k]);
-            if (din[k]) (void)hipFree(din[k]);
-            if (dout[k]) (void)hipFree(dout[k]);
-        }
-        if (s_in) (void)hipStreamDestroy(s_in);
-        if (s_run) (void)hipStreamDestroy(s_run);
-        if (s_out) (void)hipStreamDestroy(s_out);
-    };
+    int rc = pipe_ensure(c->pipe, fbytes, 0, batch);
+    if (rc) return rc;
+    PipeBufs &P = c->pipe;
+    float *hin[2] = {(float *)P.hin[0], (float *)P.hin[1]};
+    float **din = P.din;
+    int16_t **hout = P.hout, **dout = P.dout;
+    hipStream_t s_in = P.s_in, s_run = P.s_run, s_out = P.s_out;
+    hipEvent_t *e_in = P.e_in, *e_run = P.e_run, *e_out = P.e_out;
+    auto cleanup = [&]() { (void)hipDeviceSynchronize(); };
 #define Y2_TRY(expr, code) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(code, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
-    for (int k = 0; k < 2; ++k) {
-        Y2_TRY(hipHostMalloc((void **)&hin[k], fbytes, hipHostMallocDefault), YOLO2_MMAP_ERROR);
-        Y2_TRY(hipHostMalloc((void **)&hout[k], rbytes, hipHostMallocDefault), YOLO2_MMAP_ERROR);
-        Y2_TRY(hipMalloc((void **)&din[k], fbytes), YOLO2_MMAP_ERROR);
-        Y2_TRY(hipMalloc((void **)&dout[k], rbytes), YOLO2_MMAP_ERROR);
-        Y2_TRY(hipEventCreateWithFlags(&e_in[k], hipEventDisableTiming), YOLO2_ERROR);
-        Y2_TRY(hipEventCreateWithFlags(&e_run[k], hipEventDisableTiming), YOLO2_ERROR);
-        Y2_TRY(hipEventCreateWithFlags(&e_out[k], hipEventDisableTiming), YOLO2_ERROR);
-    }
-    Y2_TRY(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking), YOLO2_ERROR);
-    Y2_TRY(hipStreamCreateWithFlags(&s_run, hipStreamNonBlocking), YOLO2_ERROR);
-    Y2_TRY(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking), YOLO2_ERROR);
 
     const int chunks = (n_frames + batch - 1) / batch;
     auto frames_in_chunk = [&](int k) { return std::min(batch, n_frames - k * batch); };
@@ -1587,8 +1749,6 @@ extern "C" int yolo2_hip_run_frames_int16(yolo2_hip_ctx *c, const float *frames,
         for (int k = std::max(0, chunks - 2); k < chunks; ++k) drain(k);
         if (final_q) *final_q = q;
     }
-    (void)hipDeviceSynchronize();
-    for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(e_in[k]); (void)hipEventDestroy(e_run[k]); (void)hipEventDestroy(e_out[k]); }
     cleanup();
 #undef Y2_TRY
     return rc;

@@ -3,6 +3,8 @@
 #include "y2_host.hpp"
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -480,6 +482,42 @@ int nms_sort(std::vector<Detection> &dets, int classes, float thresh)
         }
     }
     return total;
+}
+
+// the region layer of config/yolov2.cfg (13x13, 5 anchors, 80 classes, softmax)
+Layer yolo2_region_layer()
+{
+    Layer l;
+    l.type = REGION; l.w = 13; l.h = 13; l.num = 5; l.classes = 80; l.coords = 4; l.softmax = true;
+    l.anchors = {0.57273f, 0.677385f, 1.87446f, 2.06253f, 3.33843f, 5.47434f, 7.88282f, 3.52778f, 9.77052f, 9.16828f};
+    return l;
+}
+
+std::vector<std::vector<Detection>> postprocess_batch(const int16_t *region, int batch, int final_q, const int *im_w,
+                                                      const int *im_h, float thresh, float nms, int threads)
+{
+    const Layer l = yolo2_region_layer();
+    const size_t elems = (size_t)l.num * (l.coords + 1 + l.classes) * l.h * l.w;
+    std::vector<std::vector<Detection>> out((size_t)std::max(batch, 0));
+    const float scale = std::ldexp(1.0f, -final_q);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        std::vector<float> raw(elems), proc(elems);
+        for (int f = next.fetch_add(1); f < batch; f = next.fetch_add(1)) {
+            const int16_t *r = region + (size_t)f * elems;
+            for (size_t t = 0; t < elems; ++t) raw[t] = (float)r[t] * scale;
+            region_forward(l, raw.data(), proc.data());
+            std::vector<Detection> d = region_boxes(l, proc.data(), im_w[f], im_h[f], 416, 416, thresh);
+            if (nms > 0) d.resize((size_t)nms_sort(d, l.classes, nms));
+            out[(size_t)f] = std::move(d);
+        }
+    };
+    threads = std::max(1, std::min(threads, batch));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto &t : pool) t.join();
+    return out;
 }
 
 std::vector<std::string> load_names(const std::string &path)

@@ -69,6 +69,17 @@ std::vector<Detection> region_boxes(const Layer &l, const float *out, int im_w, 
 int nms_sort(std::vector<Detection> &dets, int classes, float thresh);
 float box_iou(const Box &a, const Box &b);
 
+Layer yolo2_region_layer();
+
+// The tail of the path for a whole batch (at thousands of frames/s a single
+// thread of region + NMS is the bottleneck): int16 region tensors [batch][425][13][13] with final
+// Q -> dequantise (yolo2_model.cpp:415-417), region_forward, region_boxes, nms_sort per frame,
+// frames spread over `threads` host threads.  Per frame exactly the single-frame functions above,
+// so the results are identical to calling them in a loop.  Returns, per frame, the detections kept
+// in front by nms_sort (all w*h*num of them if nms <= 0).
+std::vector<std::vector<Detection>> postprocess_batch(const int16_t *region, int batch, int final_q, const int *im_w,
+                                                      const int *im_h, float thresh, float nms, int threads);
+
 std::vector<std::string> load_names(const std::string &path);
 
 }  // namespace y2h

@@ -1,5 +1,6 @@
 // y2_host_capi.cpp -- extern "C" doorway into the host logic for the Python tests
 // (libyolo2_host.so).  No GPU involved.
+#include <algorithm>
 #include <cstring>
 #include <exception>
 #include <string>
@@ -9,13 +10,6 @@
 using namespace y2h;
 
 static thread_local std::string g_err;
-static Layer yolo2_region_layer()
-{
-    Layer l;
-    l.type = REGION; l.w = 13; l.h = 13; l.num = 5; l.classes = 80; l.coords = 4; l.softmax = true;
-    l.anchors = {0.57273f, 0.677385f, 1.87446f, 2.06253f, 3.33843f, 5.47434f, 7.88282f, 3.52778f, 9.77052f, 9.16828f};
-    return l;
-}
 
 extern "C" {
 const char *y2h_last_error() { return g_err.c_str(); }
@@ -65,6 +59,26 @@ int y2h_boxes_nms(const float *region_proc, int im_w, int im_h, float thresh, fl
         memcpy(r + 5, d[i].prob.data(), sizeof(float) * 80);
     }
     return total;
+}
+
+// rows_out: [batch][max_rows][85] = {x, y, w, h, objectness, prob[80]}; totals[f] = detections kept for frame f
+int y2h_postprocess_batch(const int16_t *region, int batch, int final_q, const int *im_w, const int *im_h, float thresh,
+                          float nms, int threads, float *rows_out, int max_rows, int *totals)
+{
+    try {
+        auto all = postprocess_batch(region, batch, final_q, im_w, im_h, thresh, nms, threads);
+        for (int f = 0; f < batch; ++f) {
+            const auto &d = all[(size_t)f];
+            totals[f] = (int)d.size();
+            const int rows = std::min((int)d.size(), max_rows);
+            for (int i = 0; i < rows; ++i) {
+                float *r = rows_out + ((size_t)f * max_rows + i) * 85;
+                r[0] = d[i].bbox.x; r[1] = d[i].bbox.y; r[2] = d[i].bbox.w; r[3] = d[i].bbox.h; r[4] = d[i].objectness;
+                memcpy(r + 5, d[i].prob.data(), sizeof(float) * 80);
+            }
+        }
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
 
 int y2h_load_pnm(const char *path, int *whc, float *out, long capacity)

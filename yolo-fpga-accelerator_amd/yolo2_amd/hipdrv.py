@@ -30,7 +30,27 @@ EXPORTS = [
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
+    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host",
 ]
+
+
+def letterbox_u8(image_hwc: np.ndarray, net_w: int = 416, net_h: int = 416) -> np.ndarray:
+    """uint8 [h][w][3] (or [h][w]) host image -> float [3][net_h][net_w] frame, letterboxed on the GPU."""
+    im = np.ascontiguousarray(image_hwc, dtype=np.uint8)
+    ch = 1 if im.ndim == 2 else im.shape[2]
+    L = lib()
+    src, dst = C.c_uint64(0), C.c_uint64(0)
+    out = np.empty((3, net_h, net_w), dtype=np.float32)
+    check(L.yolo2_hip_alloc(im.nbytes, C.byref(src)), "alloc")
+    check(L.yolo2_hip_alloc(out.nbytes, C.byref(dst)), "alloc")
+    try:
+        check(L.yolo2_hip_memcpy_h2d(src, im.ctypes.data_as(C.c_void_p), im.nbytes), "h2d")
+        check(L.yolo2_hip_letterbox_u8(src, im.shape[1], im.shape[0], ch, dst, net_w, net_h, None), "yolo2_hip_letterbox_u8")
+        check(L.yolo2_hip_memcpy_d2h(out.ctypes.data_as(C.c_void_p), dst, out.nbytes), "d2h")
+    finally:
+        L.yolo2_hip_free(src)
+        L.yolo2_hip_free(dst)
+    return out
 
 
 class Yolo2HipError(RuntimeError):
@@ -87,6 +107,8 @@ def lib():
     L.yolo2_hip_load_weights_fp32.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     L.yolo2_hip_run_batch_fp16.argtypes = [vp, u64, i32, u64, vp]
     L.yolo2_hip_run_batch_fp16_host.argtypes = [vp, vp, i32, vp]
+    L.yolo2_hip_letterbox_u8.argtypes = [u64, i32, i32, i32, u64, i32, i32, vp]
+    L.yolo2_hip_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.memory_get_phys_addr.restype = u64
     L.memory_get_phys_addr.argtypes = [vp]
     _lib = L
@@ -254,6 +276,22 @@ class Yolo2Hip:
         check(lib().yolo2_hip_run_batch_int16_host(self._h, frames.ctypes.data_as(C.c_void_p), B,
                                                    region.ctypes.data_as(C.c_void_p), C.byref(q)),
               "yolo2_hip_run_batch_int16_host")
+        self.final_q = q.value
+        return region, q.value
+
+    def run_images_host(self, images, batch: int = 64):
+        """images: list of uint8 arrays [h][w][3] (or [h][w] grey) of arbitrary sizes -> region tensors.
+        Bytes cross PCIe, letterboxing runs on the GPU (yolo2_hip_run_images_u8_host)."""
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        n = len(imgs)
+        ch = 1 if imgs[0].ndim == 2 else imgs[0].shape[2]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        region = np.empty((n, 425, 13, 13), dtype=np.int16)
+        q = C.c_int(0)
+        check(lib().yolo2_hip_run_images_u8_host(self._h, ptrs, ws, hs, ch, n, batch, region.ctypes.data_as(C.c_void_p), C.byref(q)),
+              "yolo2_hip_run_images_u8_host")
         self.final_q = q.value
         return region, q.value
 
