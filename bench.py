@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 #   form B (MODE 1): 2 x v_dot2c 4 + v_and_or 4 + v_med3 4                       = 16
 #   form C (MODE 3): 2 x v_dot2 4 + v_ashrrev(_sdwa) 4 + half a v_pk_add_i16 2   = 14
 VALU_PEAK_TCYCLES = 256 * 4 * 2.4e9 / 1e12          # SIMD issue cycles per second at the 2.4 GHz max clock
-CYCLES_PER_STEP = {0: 20, 1: 16, 2: None, 3: 14}
+CYCLES_PER_STEP = {0: 20, 1: 16, 2: None, 3: 14, 4: 12}
 
 
 def conv_layer_bytes(l, batch):
@@ -298,19 +298,21 @@ def main():
         # SIMD issue cycles the conv steps of one batch need at the measured instruction costs
         # / cycles available in ms_per_step on 1024 SIMDs at the 2.4 GHz maximum clock
         need = 0.0
+        counts = ctx.layer_path_counts()
         for l in net.CONVS:
-            c = CYCLES_PER_STEP.get(paths[l.ord])
-            if c is None:
+            cnt = counts[l.ord]
+            if cnt[2]:              # a 64-bit block has no fixed cycle count
                 need = None
                 break
-            need += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B / 64 * c
+            mean_c = sum(cnt[k] * CYCLES_PER_STEP[k] for k in (0, 1, 3, 4)) / sum(cnt)
+            need += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B / 64 * mean_c
         valu = None
         if need is not None:
             used = need / (dt / args.steps) / 1e12
             valu = {"bound": "valu_issue", "scope": "all conv layers of one step / wall time of the step",
                     "achieved": used, "peak": VALU_PEAK_TCYCLES, "unit": "T SIMD issue cycles/s",
                     "frac": used / VALU_PEAK_TCYCLES,
-                    "note": "SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs): form C 14, "
+                    "note": "SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs): form D 12, form C 14, "
                             "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
                             "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
         traffic, traffic_src = hbm_traffic_per_launch(key[0], B)

@@ -130,14 +130,15 @@ int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_
                                      const int32_t *act_q, int n_act_q);
 
 /* 0 = 32-bit form A, 1 = 32-bit form B (pre-shifted accumulator), 3 = form C (packed int16
- * accumulators), 2 = 64-bit exact path, <0 = bad ordinal / not loaded.  All are bit-exact; the
+ * accumulators), 4 = form D (form C with the requantisation shift folded into pre-scaled weights),
+ * 2 = 64-bit exact path, <0 = bad ordinal / not loaded.  All are bit-exact; the
  * loader picks the narrowest one it can PROVE exact for the weights and Q values at hand
  * (csrc/kernels_int16.hpp explains the forms). */
 int yolo2_hip_layer_path(yolo2_hip_ctx *ctx, int conv_ordinal);
 /* The form is chosen per block of 32 output channels (a few large-weight channels must not slow
  * a whole layer down): layer_path() reports the form most blocks use, this the count per form
  * (index = the codes above). */
-int yolo2_hip_layer_path_counts(yolo2_hip_ctx *ctx, int conv_ordinal, int counts[4]);
+int yolo2_hip_layer_path_counts(yolo2_hip_ctx *ctx, int conv_ordinal, int counts[5]);
 
 /* (Re)allocates the activation tensors for exactly `batch` frames per call. */
 int yolo2_hip_set_batch(yolo2_hip_ctx *ctx, int batch);

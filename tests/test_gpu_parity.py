@@ -201,7 +201,7 @@ def test_fullnet_paths_and_64bit_fallback(monkeypatch):
     model = synth.SynthModel(seed=1)
     frame = synth.frames(7, 1)
     want = FULL["i16/std/region_raw_i16"].reshape(425, 13, 13)
-    for force in ("2", "0", "1", "3"):
+    for force in ("2", "0", "1", "3", "4"):
         monkeypatch.setenv("YOLO2_FORCE_PATH", force)
         ctx = hipdrv.Yolo2Hip(0)
         ctx.load_model(model)
@@ -216,7 +216,7 @@ def test_fullnet_paths_and_64bit_fallback(monkeypatch):
 
 
 @pytest.mark.parametrize("P", [1, 2, 4, 8])
-@pytest.mark.parametrize("path", ["0", "1", "3"])
+@pytest.mark.parametrize("path", ["0", "1", "3", "4"])
 def test_fullnet_every_tile_shape_and_form(P, path, monkeypatch):
     """Every (pixels-per-lane, arithmetic form) instantiation of the conv kernel on the whole
     network, 3 frames (so tiles straddle frame boundaries), against the reference fixture."""
@@ -227,7 +227,8 @@ def test_fullnet_every_tile_shape_and_form(P, path, monkeypatch):
     ctx = hipdrv.Yolo2Hip(0)
     ctx.load_model(model)
     ctx.set_batch(3)
-    assert all(ctx.conv_launch_info(o)["pixels_per_lane"] == min(P, 4 if path == "0" else 8) for o in range(23))
+    # (form D is never legal for layer 0 of this model: its shift of 19 exceeds 16)
+    assert all(ctx.conv_launch_info(o)["pixels_per_lane"] == min(P, 4 if path == "0" else 8) for o in range(1, 23))
     region, _ = ctx.run_batch_host(frames)
     want = FULL["i16/std/region_raw_i16"].reshape(425, 13, 13)
     assert np.array_equal(region[0], want) and np.array_equal(region[2], want)
@@ -277,6 +278,48 @@ def test_split_k_disabled_by_env(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_form_d_scaled_weights(qset, monkeypatch):
+    """Form D stores w * 2^(16-s) for the blocks whose weights leave that much int16 headroom and
+    reads every increment as the high half of the dot product.  Default selection (no forcing):
+    the standard model runs it on every layer but the first; a weight set with outliers keeps it for
+    the blocks that still fit and must stay bit-exact across the mix; reloading weights into the same
+    context must not scale twice."""
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    frames = np.concatenate([synth.frames(int(FULL["meta/frame_seed"]), 1), synth.frames(3, 2)])
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    counts = ctx.layer_path_counts()
+    if qset == "std":
+        # every block but layer 0's (shift 19 > 16) and one form-B block of ord 3
+        assert counts[0][4] == 0 and sum(sum(c) - c[4] for c in counts[1:]) <= 1, counts
+    region, _ = ctx.run_batch_host(frames)
+    assert np.array_equal(region[0], want), _diagnose(ctx, model, frames[0], 0)
+    ctx.load_model(model)                      # second load into the same context
+    region2, _ = ctx.run_batch_host(frames)
+    assert np.array_equal(region2, region)
+    ctx.close()
+    # outliers: every 5th output channel of ord 12 (256->512 3x3) gets weights up to +-20000 in a few taps
+    rng = np.random.default_rng(2)
+    w = model.w_nat[12].astype(np.int32)
+    for m in range(0, w.shape[0], 5 * 32):
+        w[m, ::7] = rng.integers(-20000, 20001, w[m, ::7].shape)
+    model.w_nat[12] = w.astype(np.int16)
+    l = net.CONVS[12]
+    model.w_reorg[12] = synth.reorg_weights(model.w_nat[12], l.c, l.n, l.size)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    c12 = ctx.layer_path_counts()[12]
+    assert sum(c12) == 16 and 0 < c12[4] < 16, c12
+    region, _ = ctx.run_batch_host(frames[:2])
+    orclib.oracle().orc_set_threads(16)
+    for f in range(2):
+        ri, _, _ = orclib.forward_i16(model, frames[f])
+        assert np.array_equal(region[f].reshape(-1), ri), _diagnose(ctx, model, frames[f], f)
+    ctx.close()
+
+
 def test_extreme_weights_select_wide_path():
     """A weight set that can overflow int32 must be routed to the 64-bit kernel by the loader."""
     model = synth.SynthModel(seed=1)
@@ -308,7 +351,8 @@ def test_mixed_forms_inside_one_layer():
     ctx = hipdrv.Yolo2Hip(0)
     ctx.load_model(model)
     counts = ctx.layer_path_counts()
-    assert sum(counts[7]) == 8 and counts[7][3] == 6 and counts[7][2] == 1, counts[7]   # 6 blocks form C, one 64-bit, one A/B
+    # 6 blocks stay in the packed forms (D where the scaled weights fit, else C), one 64-bit, one A/B
+    assert sum(counts[7]) == 8 and counts[7][3] + counts[7][4] == 6 and counts[7][2] == 1, counts[7]
     assert all(sum(c) == (l.n + 31) // 32 for c, l in zip(counts, net.CONVS)), counts   # every block is in exactly one launch
     frames = synth.frames(21, 2)
     region, _ = ctx.run_batch_host(frames)

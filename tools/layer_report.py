@@ -8,7 +8,7 @@ import numpy as np, torch
 from yolo2_amd import hipdrv, net, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-CYC = {0: 20, 1: 16, 3: 14}
+CYC = {0: 20, 1: 16, 3: 14, 4: 12}
 model = synth.SynthModel(seed=1)
 ctx = hipdrv.Yolo2Hip(0); ctx.load_model(model); ctx.set_batch(B)
 frames = torch.from_numpy(synth.frames(7, B)).cuda()

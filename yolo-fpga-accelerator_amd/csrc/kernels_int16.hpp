@@ -106,6 +106,53 @@ __device__ __forceinline__ void stepC4(int &acc01, int &acc23, const int2 x, con
           "v"(r), "s"(s));
 }
 
+// Form D (3 instructions = 12 cycles per step): form C with the shift folded into the weights.
+// If a block's weights leave k = 16 - s bits of int16 headroom, the loader stores them as w * 2^k;
+// then p' = p * 2^k and  (p' + 2^15) >> 16  ==  (p + 2^(s-1)) >> s  exactly, i.e. every increment t
+// is simply the HIGH half of the dot result.  One v_perm_b32 gathers the high halves of two
+// channels into a packed pair (replacing two shifts) and v_pk_add_i16 clamp accumulates it.
+// Hazards as in form C (DOT result -> non-DOT reader: 3 instructions in between), which is why one
+// statement covers 8 channels: every v_perm is at least 3 instructions behind its second operand's
+// last dot.  `sel` = 0x07060302: bytes 2,3 of src1 (even channel) then bytes 2,3 of src0 (odd channel).
+// (Two asm statements because one may name at most 30 operands; hipcc can only insert instructions
+// between them, which lengthens the spacing.)
+__device__ __forceinline__ void stepD8(int &acc01, int &acc23, int &acc45, int &acc67, const int2 x, const int2 *w,
+                                       const int r, const int sel)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
+        "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
+        "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
+        "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
+        "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
+        "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
+        "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
+        "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
+        "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %25, %7"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "s"(w[0].x), "s"(w[1].x), "s"(w[2].x), "s"(w[3].x), "s"(w[4].x), "s"(w[5].x), "s"(w[6].x), "s"(w[7].x),
+          "s"(w[0].y), "s"(w[1].y), "s"(w[2].y), "s"(w[3].y), "s"(w[4].y), "s"(w[5].y), "s"(w[6].y), "s"(w[7].y),
+          "v"(x.x), "v"(x.y), "v"(r));
+    asm("v_perm_b32 %4, %5, %4, %12\n\t"
+        "v_perm_b32 %6, %7, %6, %12\n\t"
+        "v_perm_b32 %8, %9, %8, %12\n\t"
+        "v_perm_b32 %10, %11, %10, %12\n\t"
+        "v_pk_add_i16 %0, %0, %4 clamp\n\t"
+        "v_pk_add_i16 %1, %1, %6 clamp\n\t"
+        "v_pk_add_i16 %2, %2, %8 clamp\n\t"
+        "v_pk_add_i16 %3, %3, %10 clamp"
+        : "+v"(acc01), "+v"(acc23), "+v"(acc45), "+v"(acc67), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5),
+          "+v"(t6), "+v"(t7)
+        : "v"(sel));
+}
+
 // Form B (4 instructions per step, needs the tighter bound checked by the host): keep the
 // accumulator pre-shifted, Bv = acc*2^s + round.  Then
 //     Bv' = clamp( ((Bv + p) & ~(2^s-1)) | round )        with bounds  {-32768,32767}*2^s + round
@@ -159,6 +206,7 @@ __device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
 // MODE 1: 32-bit form B (pre-shifted accumulator), tighter bound, 4 instructions per step.
 // MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
 // MODE 3: 32-bit form C (packed int16 accumulators, saturating packed add), 3.5 instructions per step.
+// MODE 4: form D = form C on weights pre-scaled by 2^(16-s): shift-free, 3 instructions per step.
 // NST: staging registers per thread, 256*NST >= LDS tile items.
 // GRP (1x1 convs only): channel groups staged and consumed per barrier.  A 1x1 conv has one tap per
 //      group, i.e. only 8*P steps between barriers; with GRP = 8 the loop body looks like a 3x3
@@ -254,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p][m] = b0;
         }
-        if (MODE == 3) {  // pack channel pairs (2j, 2j+1) into acc[p][j]; the host proved |bias0| <= 32767
+        if (MODE == 3 || MODE == 4) {  // pack channel pairs (2j, 2j+1) into acc[p][j]; the host proved |bias0| <= 32767
             int pk[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) pk[j] = ((int)acc[0][2 * j] & 0xffff) | ((int)acc[0][2 * j + 1] << 16);
@@ -321,7 +369,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
                 // form B gets naturally from accumulating into acc.  No instruction is emitted.
                 if (MODE == 0) asm volatile("" : "+v"(x.x) : "v"(chain));
-                if (MODE == 3) {
+                if (MODE == 4) {
+                    int a01 = (int)acc[p][0], a23 = (int)acc[p][1], a45 = (int)acc[p][2], a67 = (int)acc[p][3];
+                    stepD8(a01, a23, a45, a67, x, w, r_vgpr, 0x07060302);
+                    acc[p][0] = (acc_t)a01; acc[p][1] = (acc_t)a23; acc[p][2] = (acc_t)a45; acc[p][3] = (acc_t)a67;
+                } else if (MODE == 3) {
                     int a01 = (int)acc[p][0], a23 = (int)acc[p][1], a45 = (int)acc[p][2], a67 = (int)acc[p][3];
                     stepC4(a01, a23, x, w[0], w[1], w[2], w[3], r_vgpr, s);
                     stepC4(a45, a67, x, w[4], w[5], w[6], w[7], r_vgpr, s);
@@ -364,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             for (int t = 0; t < 4; ++t) {
                 int e = (int)acc[p][g * 4 + t];
                 if (MODE == 1) e >>= s;  // back from the pre-shifted domain
-                if (MODE == 3) {         // unpack channel g*4+t from its pair register
+                if (MODE == 3 || MODE == 4) {   // unpack channel g*4+t from its pair register
                     const int pr = (int)acc[p][(g * 4 + t) >> 1];
                     e = (t & 1) ? (pr >> 16) : (int)(short)(pr & 0xffff);
                 }
@@ -668,19 +720,40 @@ __global__ void k_weight_bound(const short *__restrict__ wpk, long n_quads, int 
 
 // Same bound per output-channel block of 32 (one workgroup per block): lets the loader pick the
 // arithmetic form per block, so a few large-weight channels do not slow the whole layer down.
-__global__ void k_weight_bound_mb(const short *__restrict__ wpk, long quads_per_mb, int *__restrict__ result)
+// result_abs: the block's largest |w| (the int16 headroom form D needs to fold the shift into the weights).
+__global__ void k_weight_bound_mb(const short *__restrict__ wpk, long quads_per_mb, int *__restrict__ result,
+                                  int *__restrict__ result_abs)
 {
-    __shared__ int red[4];
+    __shared__ int red[4], red_abs[4];
     const short *base = wpk + (long)blockIdx.x * quads_per_mb * 4;
-    int best = 0;
+    int best = 0, big = 0;
     for (long t = threadIdx.x; t < quads_per_mb; t += blockDim.x) {
         const short *w = base + t * 4;
-        best = max(best, abs((int)w[0]) + abs((int)w[1]) + abs((int)w[2]) + abs((int)w[3]));
+        const int a0 = abs((int)w[0]), a1 = abs((int)w[1]), a2 = abs((int)w[2]), a3 = abs((int)w[3]);
+        best = max(best, a0 + a1 + a2 + a3);
+        big = max(big, max(max(a0, a1), max(a2, a3)));
     }
-    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    for (int o = 32; o > 0; o >>= 1) { best = max(best, __shfl_xor(best, o)); big = max(big, __shfl_xor(big, o)); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = best; red_abs[threadIdx.x >> 6] = big; }
     __syncthreads();
-    if (threadIdx.x == 0) result[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (threadIdx.x == 0) {
+        result[blockIdx.x] = max(max(red[0], red[1]), max(red[2], red[3]));
+        result_abs[blockIdx.x] = max(max(red_abs[0], red_abs[1]), max(red_abs[2], red_abs[3]));
+    }
+}
+
+// Multiplies the packed weights of output-channel block `mb` by 2^shl[mb] (shl < 0: exact arithmetic
+// right shift back).  Used once per (re)resolution of the arithmetic forms: blocks that run form D
+// keep their weights pre-scaled by 2^(16-s).  grid = (chunks, MB).
+__global__ void k_scale_weight_blocks(short *__restrict__ wpk, long elems_per_mb, const signed char *__restrict__ shl)
+{
+    const int k = shl[blockIdx.y];
+    if (k == 0) return;
+    short *base = wpk + (long)blockIdx.y * elems_per_mb;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < elems_per_mb; t += (long)gridDim.x * blockDim.x) {
+        const int v = base[t];
+        base[t] = (short)(k > 0 ? v * (1 << k) : v >> (-k));
+    }
 }
 
 // ------------------------------------------------------------------ generic reference-layout kernels

@@ -121,8 +121,10 @@ static ShiftSpec make_shift(int s)  // core_compute.cpp:48-63: magnitude capped 
 //   |p + round| <= maxsum*32768 + round ;  |acc + scaled| <= max(32768,|bias0|) + |p + round|
 // Form B keeps acc*2^s + round in the register:  max(32768,|bias0|)*2^s + round + |p| must fit.
 // Form C packs two int16 accumulators per register and needs every increment to fit int16.
-// Returns 0 (form A), 1 (form B), 3 (form C) or 2 (64-bit); the narrowest legal form wins.
-static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
+// Form D is form C with the shift folded into the weights (w * 2^(16-s) must still be int16 and the
+// scaled dot product + 2^15 must fit int32); only offered when the caller passes the block's max |w|.
+// Returns 0 (form A), 1 (form B), 3 (form C), 4 (form D) or 2 (64-bit); the narrowest legal form wins.
+static int choose_path(int so, int sb, int maxsum, int max_abs_bias, int max_abs_w = -1)
 {
     if (so < 0) return 2;
     const ShiftSpec o = make_shift(so), b = make_shift(sb);
@@ -138,13 +140,17 @@ static int choose_path(int so, int sb, int maxsum, int max_abs_bias)
     const bool okB = (accmax << o.mag) + round + pmax <= 2147483647LL;
     // form C: every t = (p + round) >> s and the shifted bias must fit int16 (and p + round int32)
     const bool okC = okA && bias0 <= 32767 && ((pmax + round) >> o.mag) <= 32767;
+    const int k = 16 - so;
+    const bool okD = okC && max_abs_w >= 0 && k >= 0 && k <= 15 && ((long long)max_abs_w << k) <= 32767 &&
+                     (((long long)maxsum << k) * 32768 + 32768) <= 2147483647LL;
     if (okA) path = 0;
     if (okB) path = 1;
     if (okC) path = 3;
+    if (okD) path = 4;
     const char *force = getenv("YOLO2_FORCE_PATH");  // test hook: a narrower path only when it is legal, 2 always
     if (force) {
         const int f = atoi(force);
-        if (f == 2 || (f == 0 && okA) || (f == 1 && okB) || (f == 3 && okC)) path = f;
+        if (f == 2 || (f == 0 && okA) || (f == 1 && okB) || (f == 3 && okC) || (f == 4 && okD)) path = f;
     }
     return path;
 }
@@ -154,7 +160,7 @@ constexpr int kMaxTileItems = 2048;  // 8 staging registers x 256 threads (k_con
 struct ConvPlan {
     int C = 0, N = 0, K = 0, H = 0, W = 0, leaky = 0;
     int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
-    int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 2 = 64-bit
+    int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 4 = form D (C, shift-free), 2 = 64-bit
     int P = 8;
     int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
@@ -172,7 +178,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
 {
     const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
     const int npix = gin.B * gin.H * gin.W;
-    const int maxP = (p.path == 1 || p.path == 3) ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
+    const int maxP = (p.path == 1 || p.path == 3 || p.path == 4) ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
     if (forceP) {
         p.P = std::min(forceP, maxP);
     } else {
@@ -199,6 +205,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.out_base = out_base;
     a.shift = so.mag;
     a.round = (so.right && so.mag > 0) ? (1 << (so.mag - 1)) : 0;
+    if (p.path == 4) { a.shift = 16; a.round = 32768; }   // form D: these blocks' weights are stored as w * 2^(16-s)
     a.sh_right = so.right; a.sh_left = so.left;
     a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
     a.leaky = p.leaky;
@@ -264,11 +271,13 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
     }
     if (p.K == 3) {
         if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4) launch_conv_p<3, 4>(p, in, out, wpk, bias, st);
         else if (p.path == 3) launch_conv_p<3, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<3, 1>(p, in, out, wpk, bias, st);
         else launch_conv_p<3, 0>(p, in, out, wpk, bias, st);
     } else {
         if (p.path == 2) launch_conv_p<1, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4) launch_conv_p<1, 4>(p, in, out, wpk, bias, st);
         else if (p.path == 3) launch_conv_p<1, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<1, 1>(p, in, out, wpk, bias, st);
         else launch_conv_p<1, 0>(p, in, out, wpk, bias, st);
@@ -624,7 +633,8 @@ struct yolo2_hip_ctx {
     std::vector<int> weight_q, bias_q, act_q;
     ConvPlan plan[32];                 // per conv layer: the launch covering most output-channel blocks
     std::vector<ConvPlan> extra[32];   // further launches for blocks that need another arithmetic form
-    std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV];
+    std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV], maxabs_mb[YOLO2_N_CONV];
+    std::vector<signed char> wscale_mb[YOLO2_N_CONV];   // log2 of the factor each block's packed weights currently carry (form D)
     int *mb_lists = nullptr;           // device: block index lists of all split layers
     // Lanes: a batch is run as two half-batches on two internal streams (forked from / joined to the
     // caller's stream with events).  Every layer is then two concurrent launches, and the idle tail of
@@ -634,7 +644,7 @@ struct yolo2_hip_ctx {
     bool is_lane = false, laned = false;
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    int path_counts[YOLO2_N_CONV][4];
+    int path_counts[YOLO2_N_CONV][5];
     int reorg_shift = 0, final_q = 0;
     int batch = 0;
     Tensor t_in, t_out[32], t_cat;
@@ -801,10 +811,31 @@ static int resolve_q(yolo2_hip_ctx *c)
             pending = -1;
             // arithmetic form per block of 32 output channels; launches are grouped by form
             const int MB = (l.n + 31) / 32, so = p.Qa_in + p.Qw - p.Qa_out, sb = p.Qb - p.Qa_out;
-            std::vector<int> groups[4];
-            for (int mb = 0; mb < MB; ++mb) groups[choose_path(so, sb, c->maxsum_mb[ord][mb], c->maxbias_mb[ord][mb])].push_back(mb);
+            std::vector<int> groups[5];
+            std::vector<signed char> delta((size_t)MB, 0);
+            bool rescale = false;
+            if (c->wscale_mb[ord].size() != (size_t)MB) c->wscale_mb[ord].assign((size_t)MB, 0);
+            for (int mb = 0; mb < MB; ++mb) {
+                const int path = choose_path(so, sb, c->maxsum_mb[ord][mb], c->maxbias_mb[ord][mb],
+                                             c->maxabs_mb[ord].empty() ? -1 : c->maxabs_mb[ord][mb]);
+                groups[path].push_back(mb);
+                const int want = path == 4 ? 16 - so : 0;   // form D blocks keep w * 2^(16-s) in the packed buffer
+                delta[(size_t)mb] = (signed char)(want - c->wscale_mb[ord][(size_t)mb]);
+                rescale |= delta[(size_t)mb] != 0;
+                c->wscale_mb[ord][(size_t)mb] = (signed char)want;
+            }
+            if (rescale && !c->is_lane) {   // lanes share the parent's packed weights (and reach the same decisions)
+                signed char *dd = nullptr;
+                HIP_TRY(hipMalloc((void **)&dd, (size_t)MB), YOLO2_MMAP_ERROR);
+                HIP_TRY(hipMemcpy(dd, delta.data(), (size_t)MB, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+                const long per_mb = packed_weight_elems(l.c, l.n, l.size) / MB;
+                hipLaunchKernelGGL(k_scale_weight_blocks, dim3(std::min<unsigned>(blocks_for(per_mb, 256), 64), MB), dim3(256), 0,
+                                   nullptr, c->wpk + c->wpk_off[ord], per_mb, dd);
+                HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+                (void)hipFree(dd);
+            }
             int dom = 0;
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 5; ++k) {
                 c->path_counts[ord][k] = (int)groups[k].size();
                 if (groups[k].size() > groups[dom].size()) dom = k;
             }
@@ -825,7 +856,7 @@ static int resolve_q(yolo2_hip_ctx *c)
                 p.mb_count = (int)groups[dom].size();
                 p.args.mb_list = (const int *)(uintptr_t)lists.size();   // offset for now, pointer once uploaded
                 lists.insert(lists.end(), groups[dom].begin(), groups[dom].end());
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < 5; ++k) {
                     if (k == dom || groups[k].empty()) continue;
                     ConvPlan e = p;
                     e.path = k;
@@ -888,12 +919,13 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
     HIP_TRY(hipMalloc((void **)&c->wpk, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&c->bias_pk, (size_t)btot * 2), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMemset(c->bias_pk, 0, (size_t)btot * 2), YOLO2_DMA_ERROR);
-    int *bound = nullptr, *bound_mb = nullptr;
+    int *bound = nullptr, *bound_mb = nullptr, *bound_abs = nullptr;
     int mb_total = 0;
     for (int i = 0; i < 32; ++i)
         if (kNet[i].type == L_CONV) mb_total += (kNet[i].n + 31) / 32;
     HIP_TRY(hipMalloc((void **)&bound, sizeof(int) * YOLO2_N_CONV), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&bound_mb, sizeof(int) * mb_total), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bound_abs, sizeof(int) * mb_total), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMemset(bound, 0, sizeof(int) * YOLO2_N_CONV), YOLO2_DMA_ERROR);
     int mb_off = 0;
     std::vector<int> mb_offs;
@@ -911,7 +943,8 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
                            (const short *)(c->wpk + c->wpk_off[ord]), n / 4, bound + ord);
         const int MB = (l.n + 31) / 32;
         hipLaunchKernelGGL(k_weight_bound_mb, dim3(MB), dim3(256), 0, nullptr, (const short *)(c->wpk + c->wpk_off[ord]),
-                           n / 4 / MB, bound_mb + mb_off);
+                           n / 4 / MB, bound_mb + mb_off, bound_abs + mb_off);
+        c->wscale_mb[ord].assign((size_t)MB, 0);   // freshly packed: unscaled
         mb_offs.push_back(mb_off);
         mb_off += MB;
         HIP_TRY(hipMemcpyAsync(c->bias_pk + c->bias_off[ord], b_dev + boff, (size_t)l.n * 2, hipMemcpyDeviceToDevice, nullptr),
@@ -931,18 +964,21 @@ static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, c
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
     HIP_TRY(hipMemcpy(c->maxsum, bound, sizeof(int) * YOLO2_N_CONV, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
     {
-        std::vector<int> hm(mb_total);
+        std::vector<int> hm(mb_total), ha(mb_total);
         HIP_TRY(hipMemcpy(hm.data(), bound_mb, sizeof(int) * mb_total, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+        HIP_TRY(hipMemcpy(ha.data(), bound_abs, sizeof(int) * mb_total, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
         int o = 0;
         for (int i = 0; i < 32; ++i)
             if (kNet[i].type == L_CONV) {
                 const int MB = (kNet[i].n + 31) / 32;
                 c->maxsum_mb[o].assign(hm.begin() + mb_offs[o], hm.begin() + mb_offs[o] + MB);
+                c->maxabs_mb[o].assign(ha.begin() + mb_offs[o], ha.begin() + mb_offs[o] + MB);
                 o++;
             }
     }
     (void)hipFree(bound);
     (void)hipFree(bound_mb);
+    (void)hipFree(bound_abs);
     {
         const int rq = resolve_q(c);
         if (rq) return rq;
@@ -1000,10 +1036,10 @@ extern "C" int yolo2_hip_layer_path(yolo2_hip_ctx *c, int ord)
     return -1;
 }
 
-extern "C" int yolo2_hip_layer_path_counts(yolo2_hip_ctx *c, int ord, int counts[4])
+extern "C" int yolo2_hip_layer_path_counts(yolo2_hip_ctx *c, int ord, int counts[5])
 {
     if (!c || !c->weights_loaded || ord < 0 || ord >= YOLO2_N_CONV || !counts) return YOLO2_ERROR;
-    for (int k = 0; k < 4; ++k) counts[k] = c->path_counts[ord][k];
+    for (int k = 0; k < 5; ++k) counts[k] = c->path_counts[ord][k];
     return YOLO2_SUCCESS;
 }
 
@@ -1099,6 +1135,7 @@ static int make_lane(yolo2_hip_ctx *p, yolo2_hip_ctx **out)
     for (int o = 0; o < YOLO2_N_CONV; ++o) {
         l->maxsum_mb[o] = p->maxsum_mb[o];
         l->maxbias_mb[o] = p->maxbias_mb[o];
+        l->maxabs_mb[o] = p->maxabs_mb[o];
     }
     l->weight_q = p->weight_q;
     l->bias_q = p->bias_q;

@@ -252,7 +252,7 @@ class Yolo2Hip:
     def layer_path_counts(self):
         out = []
         for o in range(len(net.CONVS)):
-            v = (C.c_int * 4)()
+            v = (C.c_int * 5)()
             check(lib().yolo2_hip_layer_path_counts(self._h, o, v), "yolo2_hip_layer_path_counts")
             out.append(list(v))
         return out
