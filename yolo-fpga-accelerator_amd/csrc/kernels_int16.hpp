@@ -243,6 +243,9 @@ __device__ inline void xcd_partition(int xm_log2, int &tile, int &yb)
     }
 }
 
+#ifndef PREX_MAX_P
+#define PREX_MAX_P 2
+#endif
 template <int KS, int P, int MODE, int NST, int GRP = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                    const int2 *__restrict__ wpk,
@@ -355,6 +358,18 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             if (i < LtG) stage[k] = src[src_off(i)];
         }
         const char *tile = lds_b + (cg & 1) * buf_items * 8;
+        // Small tiles (P <= 2): fetch the whole group's input values up front, so the LDS latency of a
+        // tap is not exposed when few wavefronts are resident (the tail of a launch at modest batch).
+        constexpr bool PREX = (MODE == 3 || MODE == 4) && P <= PREX_MAX_P;
+        int2 xv[PREX ? KK : 1][P];
+        if (PREX) {
+#pragma unroll
+            for (int tap = 0; tap < KK; ++tap)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    xv[tap][p] = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
+                                            : *reinterpret_cast<const int2 *>(tile + tap * a.lt_max * 8 + rowaddr[p][0]);
+        }
 #pragma unroll
         for (int tap = 0; tap < KK; ++tap) {
             int2 w[8];
@@ -362,7 +377,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                int2 x = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
+                int2 x;
+                if (PREX) x = xv[tap][p];
+                else x = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
                                     : *reinterpret_cast<const int2 *>(tile + tap * a.lt_max * 8 + rowaddr[p][0]);
                 // Form A's dot products do not depend on the accumulators, so hipcc would compute
                 // all 72x8 of a group up front (hundreds of live registers, SGPR spills).  An empty
