@@ -12,7 +12,7 @@ STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 {
   echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline $*"
   echo "# bench line:"; tail -1 "$OUT/bench.json"
-  echo "# kernel stats (Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev):"
+  echo "# kernel stats of the WHOLE run (weight load, set_batch autotune launches of every tile shape, warm-up and timed steps):"
   python3 - "$STATS" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -21,5 +21,8 @@ for r in rows[:25]:
     name = name.replace("HIP_vector_type<int, 2u>", "int2")[:110]
     print(f'{name:110s} calls={r["Calls"]:>6s} total_ms={float(r["TotalDurationNs"])/1e6:10.3f} avg_us={float(r["AverageNs"])/1e3:10.2f} pct={float(r["Percentage"]):6.2f}')
 PY
+  TRACE=$(find "$OUT" -name "*kernel_trace.csv" | head -1)
+  STEPS=$(python3 -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['steps'])")
+  python3 tools/steady_stats.py "$TRACE" "$STEPS" || true
 } > "$PWD/gpurun_out/prof_${TAG}_summary.txt"
 cat "$PWD/gpurun_out/prof_${TAG}_summary.txt"
