@@ -404,6 +404,185 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
     }
 }
 
+// ---- halo-tile variant for 3x3 layers (BM = 256, 8 wavefronts) -------------------------------
+// The LDS-DMA kernel above is bound by operand movement: it stages a fresh A tile (128 pixels x 64
+// channels) for every one of the 9 taps although the taps read the SAME pixels shifted by one row
+// or column - at 100 % MFMA rate that asks the vector memory path for its full 64 B/clk/CU.  Here
+// the input tile of one 64-channel chunk is staged ONCE with its halo, as the contiguous run of
+// flat items [fo(q0) - Wp - 1, fo(q0 + 255) + Wp + 1] (the int16 kernel's tile), and the nine taps
+// read their A fragments from it at row offsets {-Wp-1 .. +Wp+1}; only the 128 x 64 weight tile is
+// staged per tap.  Staged bytes per FLOP drop 3.3x (A: 256 -> ~37 B per k-element and pixel-tile,
+// B unchanged but shared by twice the pixels).  K order is channel-chunk-major, tap-minor (a
+// different fp32 summation order than the kernels above; same tolerance).
+// Same XOR swizzle as above, keyed on the LDS row:  slot = chunk ^ ((row >> 1) & 7).
+template <int BN, int NB>
+__global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+                                                        const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                        const ConvF16Args a, const int lt_rows)
+{
+    constexpr int BM = 256, BK = 64, ROWH = BK, NW = 8;
+    // BN = 128: 4 x 2 wavefronts of 64 x 64, NB = 3 weight-tile buffers;
+    // BN = 256: 2 x 4 wavefronts of 128 x 64 (twice the MFMAs per barrier and per A-fragment read), NB = 2
+    constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / 32;
+    constexpr int BG = BN / 8 / NW;                                // B fill instructions per wavefront and tap
+    constexpr int kCt = BN + 8;                                    // halves per row of the epilogue staging tile
+    static_assert((MT == 2 || MT == 4) && BG >= 1 && (NB == 2 || NB == 3), "tile shape");
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    _Float16 *As = smem_h;                                   // [2][lt_rows][64]
+    _Float16 *Bs = smem_h + (size_t)2 * lt_rows * ROWH;      // [NB][BN][64]: with NB = 3 the weight tile of tap t+2 is in flight while t is multiplied
+    int *fo_s = reinterpret_cast<int *>(Bs + NB * BN * ROWH); // [BM]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int HW = a.H * a.W;
+    const int q0 = (blockIdx.x / a.n_tiles) * BM;
+    const int n0 = (blockIdx.x % a.n_tiles) * BN;
+    const int halo = a.Wp + 1;
+    const int tile_start = flat_of_h(q0, HW, a.W, a.Wp, a.PL) - halo;
+
+    if (tid < BM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    __syncthreads();
+
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int NA = lt_rows / 8;                 // 8-row groups of the A tile (lt_rows is a multiple of 8)
+    const int a_iters = (NA + NW - 1) / NW;
+    size_t b_src[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave * BG + i) * 8 + lrow;
+        b_src[i] = (size_t)(n0 + row) * 9 * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+    }
+    auto fill_a = [&](int buf, int c0) {        // the whole halo tile of one 64-channel chunk
+        for (int it = 0; it < a_iters; ++it) {
+            const int g = wave + it * NW;
+            if (g < NA) {
+                const int row = g * 8 + lrow;
+                const size_t src = ((size_t)kLead + tile_start + row) * a.Cp_in + c0 + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(act + src), (lds_void_t *)(As + ((size_t)buf * lt_rows + g * 8) * ROWH),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    auto fill_b = [&](int buf, int tap, int c0) {
+        const long bo = (long)tap * a.Cp_in + c0;
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(wh + b_src[i] + bo),
+                                             (lds_void_t *)(Bs + ((size_t)buf * BN + (wave * BG + i) * 8) * ROWH), 16, 0, 0);
+    };
+
+    float16_t acc[MT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int lo[MT];                                  // LDS row of this lane's A rows at the centre tap
+#pragma unroll
+    for (int t = 0; t < MT; ++t) lo[t] = fo_s[wm * (32 * MT) + t * 32 + frow] - tile_start;
+    int brow[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) brow[t] = wn * 64 + t * 32 + frow;
+
+    const int csteps = a.Cp_in / BK;
+    const int nsteps = csteps * 9;
+    fill_a(0, 0);
+    fill_b(0, 0, 0);
+    if (NB == 3) fill_b(1, 1, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    int step = 0, cur = 0;                // cur = step % NB
+    int n_tap = NB - 1, n_c0 = 0;         // (tap, channel offset) of step + NB - 1
+    for (int ci = 0; ci < csteps; ++ci) {
+        const int abuf = ci & 1;
+        if (ci + 1 < csteps) fill_a(abuf ^ 1, (ci + 1) * BK);   // lands during the nine taps of this chunk
+        const _Float16 *At = As + (size_t)abuf * lt_rows * ROWH;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap, ++step) {
+            const bool more = step + NB - 1 < nsteps;
+            if (more) {
+                fill_b(cur == 0 ? NB - 1 : cur - 1, n_tap, n_c0);   // buffer (step + NB - 1) % NB: last read in step - 1
+                if (++n_tap == 9) { n_tap = 0; n_c0 += BK; }
+            }
+            const int toff = (tap / 3 - 1) * a.Wp + (tap % 3 - 1);
+            int arow[MT], asw[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t) { arow[t] = lo[t] + toff; asw[t] = (arow[t] >> 1) & 7; }
+            const _Float16 *Bt = Bs + (size_t)cur * BN * ROWH;
+            half8_t af[2][MT], bf[2][2];
+            auto read_frags = [&](int kk, int set) {
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    af[set][t] = *reinterpret_cast<const half8_t *>(At + (size_t)arow[t] * ROWH + (((kk * 2 + fhalf) ^ asw[t]) * 8));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    bf[set][t] = *reinterpret_cast<const half8_t *>(Bt + (size_t)brow[t] * ROWH + (((kk * 2 + fhalf) ^ ((brow[t] >> 1) & 7)) * 8));
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            }
+            // interleave: the fragment reads of k-slice kk+1 go out between the MFMAs of slice kk
+            __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+#pragma unroll
+            for (int kk = 0; kk + 1 < BK / 16; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+            // Loads return in order: all but the weight tile issued in THIS step (BG instructions per wave) have
+            // landed, i.e. step + 1's weight tile and, in a chunk's first tap, the next chunk's input tile.
+            if (more && NB == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BG) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur = cur == NB - 1 ? 0 : cur + 1;
+        }
+    }
+
+    // epilogue: bias + leaky, transposed through LDS into 16-byte stores (the staging arena is free now)
+    _Float16 (*Ct)[kCt] = reinterpret_cast<_Float16 (*)[kCt]>(smem_h);
+    int fo_r[BM / (512 / (BN / 8))];   // fo_s lives behind the arena the Ct tile may overlap: keep what this thread needs
+    constexpr int CH = BN / 8, ROWS_PER_PASS = 512 / CH;
+    const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
+#pragma unroll
+    for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) fo_r[rr] = fo_s[r0 + rr * ROWS_PER_PASS];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = wn * 64 + j * 32 + (lane & 31);
+        const float bv = bias[n0 + col];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r] + bv;
+                if (a.leaky && v < 0.f) v *= 0.1f;
+                Ct[row][col] = (_Float16)v;
+            }
+    }
+    __syncthreads();
+    if (ch0 < a.n_store) {
+#pragma unroll
+        for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
+            const int row = r0 + rr * ROWS_PER_PASS;
+            if (q0 + row >= a.npix) continue;
+            const half8_t v = *reinterpret_cast<const half8_t *>(&Ct[row][chunk * 8]);
+            *reinterpret_cast<half8_t *>(out + ((size_t)kLead + fo_r[rr]) * a.Cp_out + a.out_ch_off + ch0) = v;
+        }
+    }
+}
+
 // Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:
 // K = 27 is too thin for the matrix cores, and the 416x416x32 intermediate is never needed again
 // (yolov2.cfg: layer 1 is its only consumer), so this kernel keeps it in registers.  One lane owns

@@ -1691,8 +1691,40 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                 else hipLaunchKernelGGL((k_conv_f16<128, 64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             } else {
                 a.n_tiles = round_up(l.n, kBN) / kBN;
-                // (a 256x128 tile with 8 wavefronts was measured 8 % SLOWER than 128x128 with two
-                //  workgroups per CU: the K loop is bound by its barrier/LDS cadence, not by operand reuse)
+                // 3x3 layers: halo-tile kernel (input tile staged once per 64-channel chunk, nine taps read it
+                // shifted) wherever its LDS arena fits: 2 x lt_rows x 128 B (A) + 3 x 128 x 128 B (B) + fo table
+                if (glds && l.size == 3 && l.n % kBN == 0 && !getenv("YOLO2_F16_NO_HALO")) {
+                    const ActGeom g = make_geom(l.c, l.h, l.w, B);
+                    const int lt_rows = round_up(tile_items_bound(g, 256, g.Wp + 1), 8);
+                    const size_t a_bytes = (size_t)2 * lt_rows * 128, fo_bytes = 256 * sizeof(int), cap = 160 * 1024;
+                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes;
+                    const bool wide = l.n % 256 == 0 && lds256 <= cap && a_bytes + (size_t)2 * 256 * 128 >= (size_t)256 * 264 * 2 &&
+                                      !getenv("YOLO2_F16_NO_WIDE");
+                    const bool fits = g.Wp + 1 <= kLead && (wide || (lds128 <= cap && a_bytes >= (size_t)256 * kCtRow * 2));
+                    if (fits) {
+                        static bool attr_set = false;
+                        if (!attr_set) {
+                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)cap), YOLO2_ERROR);
+                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)cap), YOLO2_ERROR);
+                            attr_set = true;
+                        }
+                        if (wide) {
+                            a.n_tiles = l.n / 256;
+                            const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
+                            hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
+                        } else {
+                            const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
+                            hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);
+                        }
+                        if (i != 30) cur = &c->h_out[i];
+                        ord++;
+                        break;
+                    }
+                }
+                // (a 256x128 tile with 8 wavefronts and per-tap A staging was measured 8 % SLOWER than 128x128
+                //  with two workgroups per CU: without the halo reuse the bigger tile only adds barrier cost)
                 const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
                 if (glds) hipLaunchKernelGGL((k_conv_f16_glds<128>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
