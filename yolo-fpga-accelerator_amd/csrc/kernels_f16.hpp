@@ -408,13 +408,17 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
 // The LDS-DMA kernel above is bound by operand movement: it stages a fresh A tile (128 pixels x 64
 // channels) for every one of the 9 taps although the taps read the SAME pixels shifted by one row
 // or column - at 100 % MFMA rate that asks the vector memory path for its full 64 B/clk/CU.  Here
-// the input tile of one 64-channel chunk is staged ONCE with its halo, as the contiguous run of
-// flat items [fo(q0) - Wp - 1, fo(q0 + 255) + Wp + 1] (the int16 kernel's tile), and the nine taps
-// read their A fragments from it at row offsets {-Wp-1 .. +Wp+1}; only the 128 x 64 weight tile is
-// staged per tap.  Staged bytes per FLOP drop 3.3x (A: 256 -> ~37 B per k-element and pixel-tile,
-// B unchanged but shared by twice the pixels).  K order is channel-chunk-major, tap-minor (a
-// different fp32 summation order than the kernels above; same tolerance).
-// Same XOR swizzle as above, keyed on the LDS row:  slot = chunk ^ ((row >> 1) & 7).
+// the input tile of one 64-channel chunk is staged ONCE with its halo and the nine taps read their
+// A fragments from it at row offsets {-W-1 .. +W+1}; only the weight tile is staged per tap.
+// Staged bytes per FLOP drop ~3x.  K order is channel-chunk-major, tap-minor (a different fp32
+// summation order than the kernels above; same tolerance).
+// The tile is DENSE in pixel index (LDS row R = pixel q0 - W - 1 + R, no pad rows): the lanes of a
+// ds_read_b128 group then always read 16 rows with distinct residues mod 16, which the XOR swizzle
+// (slot = chunk ^ ((row >> 1) & 7), keyed on the LDS row) maps to 16 distinct bank groups for every
+// tap.  (A first version staged the flat run incl. the layout's pad pixels: wherever a lane group
+// straddled an image-row end its rows skipped one and 39 % of the LDS cycles were bank conflicts.)
+// A dense tile has no zeros for out-of-image taps, so a lane whose tap leaves the image reads a
+// dedicated all-zero row instead (one v_cndmask on the address; identical addresses broadcast).
 template <int BN, int NB>
 __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
@@ -426,9 +430,10 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
     constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / 32;
     constexpr int BG = BN / 8 / NW;                                // B fill instructions per wavefront and tap
     constexpr int kCt = BN + 8;                                    // halves per row of the epilogue staging tile
+    constexpr int kMaxAIters = 8;                                  // A fill instructions per wavefront (host: lt_rows <= 8*8*8 + 8)
     static_assert((MT == 2 || MT == 4) && BG >= 1 && (NB == 2 || NB == 3), "tile shape");
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
-    _Float16 *As = smem_h;                                   // [2][lt_rows][64]
+    _Float16 *As = smem_h;                                   // [2][lt_rows][64]; rows lt_rows-8.. of each buffer stay zero
     _Float16 *Bs = smem_h + (size_t)2 * lt_rows * ROWH;      // [NB][BN][64]: with NB = 3 the weight tile of tap t+2 is in flight while t is multiplied
     int *fo_s = reinterpret_cast<int *>(Bs + NB * BN * ROWH); // [BM]
 
@@ -437,15 +442,26 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
     const int HW = a.H * a.W;
     const int q0 = (blockIdx.x / a.n_tiles) * BM;
     const int n0 = (blockIdx.x % a.n_tiles) * BN;
-    const int halo = a.Wp + 1;
-    const int tile_start = flat_of_h(q0, HW, a.W, a.Wp, a.PL) - halo;
+    const int d0 = q0 - a.W - 1;                 // pixel index of LDS row 0
+    const int NA = lt_rows / 8 - 1;              // 8-row groups filled by DMA; the last group is the zero rows
+    const int zrow = NA * 8;
 
     if (tid < BM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    if (tid < 2 * 8 * 8) {                       // zero rows of both buffers: 2 x 8 rows x 128 B = 128 x 16 B
+        const int buf = tid >> 6, r = (tid >> 3) & 7, c = tid & 7;
+        *reinterpret_cast<int4 *>(As + ((size_t)buf * lt_rows + zrow + r) * ROWH + c * 8) = make_int4(0, 0, 0, 0);
+    }
     __syncthreads();
 
     const int lrow = lane >> 3, lslot = lane & 7;
-    const int NA = lt_rows / 8;                 // 8-row groups of the A tile (lt_rows is a multiple of 8)
     const int a_iters = (NA + NW - 1) / NW;
+    size_t a_src[kMaxAIters];                    // source of this lane's 16 bytes in each of its A fill instructions
+#pragma unroll
+    for (int it = 0; it < kMaxAIters; ++it) {
+        const int row = (wave + it * NW) * 8 + lrow;
+        const int d = min(max(d0 + row, 0), a.npix - 1);     // rows outside the tensor are only ever read masked
+        a_src[it] = ((size_t)kLead + flat_of_h(d, HW, a.W, a.Wp, a.PL)) * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+    }
     size_t b_src[BG];
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
@@ -453,14 +469,12 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
         b_src[i] = (size_t)(n0 + row) * 9 * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
     }
     auto fill_a = [&](int buf, int c0) {        // the whole halo tile of one 64-channel chunk
-        for (int it = 0; it < a_iters; ++it) {
+#pragma unroll
+        for (int it = 0; it < kMaxAIters; ++it) {
             const int g = wave + it * NW;
-            if (g < NA) {
-                const int row = g * 8 + lrow;
-                const size_t src = ((size_t)kLead + tile_start + row) * a.Cp_in + c0 + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(act + src), (lds_void_t *)(As + ((size_t)buf * lt_rows + g * 8) * ROWH),
-                                                 16, 0, 0);
-            }
+            if (it < a_iters && g < NA)
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(act + a_src[it] + c0),
+                                                 (lds_void_t *)(As + ((size_t)buf * lt_rows + g * 8) * ROWH), 16, 0, 0);
         }
     };
     auto fill_b = [&](int buf, int tap, int c0) {
@@ -481,8 +495,20 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
 
     const int frow = lane & 31, fhalf = lane >> 5;
     int lo[MT];                                  // LDS row of this lane's A rows at the centre tap
+    unsigned tapmask[MT];                        // bit t: tap t of that pixel lies inside the image
 #pragma unroll
-    for (int t = 0; t < MT; ++t) lo[t] = fo_s[wm * (32 * MT) + t * 32 + frow] - tile_start;
+    for (int t = 0; t < MT; ++t) {
+        const int m = wm * (32 * MT) + t * 32 + frow;
+        lo[t] = m + a.W + 1;
+        const int q = min(q0 + m, a.npix - 1), rem = q % HW, y = rem / a.W, x = rem - y * a.W;
+        unsigned mk = 0;
+#pragma unroll
+        for (int tp = 0; tp < 9; ++tp) {
+            const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+            if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) mk |= 1u << tp;
+        }
+        tapmask[t] = mk;
+    }
     int brow[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) brow[t] = wn * 64 + t * 32 + frow;
@@ -497,6 +523,7 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
 
     int step = 0, cur = 0;                // cur = step % NB
     int n_tap = NB - 1, n_c0 = 0;         // (tap, channel offset) of step + NB - 1
+    // (fetching the next tap's first A fragments ahead of the barrier that ends a tap was tried: -1 %)
     for (int ci = 0; ci < csteps; ++ci) {
         const int abuf = ci & 1;
         if (ci + 1 < csteps) fill_a(abuf ^ 1, (ci + 1) * BK);   // lands during the nine taps of this chunk
@@ -508,10 +535,13 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
                 fill_b(cur == 0 ? NB - 1 : cur - 1, n_tap, n_c0);   // buffer (step + NB - 1) % NB: last read in step - 1
                 if (++n_tap == 9) { n_tap = 0; n_c0 += BK; }
             }
-            const int toff = (tap / 3 - 1) * a.Wp + (tap % 3 - 1);
+            const int toff = (tap / 3 - 1) * a.W + (tap % 3 - 1);
             int arow[MT], asw[MT];
 #pragma unroll
-            for (int t = 0; t < MT; ++t) { arow[t] = lo[t] + toff; asw[t] = (arow[t] >> 1) & 7; }
+            for (int t = 0; t < MT; ++t) {
+                arow[t] = ((tapmask[t] >> tap) & 1) ? lo[t] + toff : zrow;
+                asw[t] = (arow[t] >> 1) & 7;
+            }
             const _Float16 *Bt = Bs + (size_t)cur * BN * ROWH;
             half8_t af[2][MT], bf[2][2];
             auto read_frags = [&](int kk, int set) {
@@ -771,6 +801,83 @@ __global__ void k_pack_weights_f16(const float *__restrict__ src, _Float16 *__re
         v = src[(long)m0 * C * KK + (long)tm_min * n0 * KK + (long)tap * tm_min * tn_min + tm * tn_min + tn];
     }
     dst[t] = (_Float16)v;
+}
+
+// Layers 0 + 1 on the matrix cores.  K = 27 is thin, but the fp32-VALU kernel above still needs
+// 76 GFLOP of plain FMAs per 256 frames (1.25 ms, 12 % of the fp16 pass); as an im2col GEMM with K
+// padded to 32 it is two v_mfma_f32_32x32x16_f16 per 32 pixels x 32 channels.  One workgroup owns a
+// 16 x 32 tile of conv outputs (8 x 16 pooled pixels): the 18 x 34 x 3 input patch is converted to
+// fp16 into LDS once, and each A fragment is gathered from it with 16-bit LDS reads (k = c*9 + tap
+// -> patch[c][y + tap/3][x + tap%3]; rows k >= 27 of B are zero, so their A entries may be any
+// finite patch value).  A 32-row MFMA block is 2 conv rows x 16 conv columns ordered
+// row = 4*pooled_col + 2*dy + dx, which puts the four members of every 2x2 pool window into
+// registers r&3 = 0..3 of ONE lane (C layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)): the pool is an
+// in-lane max, then bias + leaky (monotonic, so it commutes with the max).
+// w0: [27][32] fp32 (k = c*9 + tap), bias0: [32] fp32; out = layer-1 items of 32 halves.
+__global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict__ frames, const float *__restrict__ w0,
+                                                          const float *__restrict__ bias0, _Float16 *__restrict__ out, int H,
+                                                          int W, int oWp, int oPL)
+{
+    constexpr int TR = 16, TC = 32, PR = TR + 2, PC = TC + 2, PCS = 36;   // patch rows / cols / row stride (halves)
+    __shared__ _Float16 patch[3 * PR * PCS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = W / TC, tiles_y = H / TR;
+    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
+
+    // B fragments (weights), constant for the whole kernel: lane (n = lane & 31, h = lane >> 5) holds B[16kk + 8h + j][n]
+    const int n = lane & 31, h = lane >> 5;
+    half8_t bfrag[2];
+    int aoff[2][8];   // patch offset (halves) of A element (kk, j) relative to the pixel's top-left tap
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * kk + 8 * h + j;
+            bfrag[kk][j] = k < 27 ? (_Float16)w0[k * 32 + n] : (_Float16)0.f;
+            const int c = k / 9, tap = k - c * 9;
+            aoff[kk][j] = k < 27 ? (c * PR + tap / 3) * PCS + tap % 3 : 0;
+        }
+    const float bv = bias0[n];
+
+    // stage the patch: rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32, zero outside the image
+    const float *fb = frames + (size_t)b * 3 * H * W;
+    for (int i = tid; i < 3 * PR * PC; i += 256) {
+        const int c = i / (PR * PC), r = i - c * (PR * PC), py = r / PC, px = r - py * PC;
+        const int sy = ty0 + py - 1, sx = tx0 + px - 1;
+        const float v = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? fb[((size_t)c * H + sy) * W + sx] : 0.f;
+        patch[(c * PR + py) * PCS + px] = (_Float16)v;
+    }
+    __syncthreads();
+
+    // this lane's pixel inside an MFMA block: row r = 4*pc + 2*dy + dx
+    const int r = lane & 31, dx = r & 1, dy = (r >> 1) & 1, pc = r >> 2;
+    const int oW = W / 2;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int prow = wave * 2 + (mb >> 1), chalf = mb & 1;            // pooled row 0..7, column half 0..1 of the tile
+        const int base = (2 * prow + dy) * PCS + (chalf * 16 + 2 * pc + dx);   // top-left tap of this lane's conv pixel
+        float16_t acc;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8_t af;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) af[j] = patch[base + aoff[kk][j]];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[kk], acc, 0, 0, 0);
+        }
+        // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
+        const int oy = ty0 / 2 + prow;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
+            if (v < 0.f) v *= 0.1f;
+            const int ox = tx0 / 2 + chalf * 8 + 2 * g + h;
+            out[((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + n] = (_Float16)v;
+        }
+    }
+    (void)oW;
 }
 
 // layer-0 weights for k_conv0_pool_f16: weights_reorg fp32 (C=3, N=32, 3x3) -> w0[k = c*9 + tap][n]

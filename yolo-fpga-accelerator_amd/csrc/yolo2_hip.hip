@@ -1653,9 +1653,14 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     if (ev) (void)hipEventRecord(ev[0], st);
     {   // layers 0+1 fused: conv 3->32 + leaky + 2x2 pool straight from the float frames
         const auto &g = c->h_out[1];
-        hipLaunchKernelGGL(k_conv0_pool_f16, dim3(blocks_for((long)B * g.H * g.W, 256), 2), dim3(256), 0, st,
-                           (const float *)(uintptr_t)frames_dev, (const float *)c->w0f, (const float *)(c->w0f + 27 * 32), g.d, B,
-                           416, 416, g.Wp, g.PL);
+        if (!getenv("YOLO2_F16_NO_MFMA0"))   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
+            hipLaunchKernelGGL(k_conv0_pool_mfma, dim3((unsigned)B * (416 / 16) * (416 / 32)), dim3(256), 0, st,
+                               (const float *)(uintptr_t)frames_dev, (const float *)c->w0f, (const float *)(c->w0f + 27 * 32), g.d,
+                               416, 416, g.Wp, g.PL);
+        else
+            hipLaunchKernelGGL(k_conv0_pool_f16, dim3(blocks_for((long)B * g.H * g.W, 256), 2), dim3(256), 0, st,
+                               (const float *)(uintptr_t)frames_dev, (const float *)c->w0f, (const float *)(c->w0f + 27 * 32), g.d, B,
+                               416, 416, g.Wp, g.PL);
         if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
     }
     int ord = 1;
@@ -1694,19 +1699,25 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                 // 3x3 layers: halo-tile kernel (input tile staged once per 64-channel chunk, nine taps read it
                 // shifted) wherever its LDS arena fits: 2 x lt_rows x 128 B (A) + 3 x 128 x 128 B (B) + fo table
                 if (glds && l.size == 3 && l.n % kBN == 0 && !getenv("YOLO2_F16_NO_HALO")) {
-                    const ActGeom g = make_geom(l.c, l.h, l.w, B);
-                    const int lt_rows = round_up(tile_items_bound(g, 256, g.Wp + 1), 8);
+                    // dense tile: 256 pixels + W+1 on either side, rounded to 8-row groups, + 8 zero rows
+                    const int lt_rows = round_up(256 + 2 * (l.w + 1), 8) + 8;
                     const size_t a_bytes = (size_t)2 * lt_rows * 128, fo_bytes = 256 * sizeof(int), cap = 160 * 1024;
-                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes;
+                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes,
+                                 lds128s = a_bytes + (size_t)2 * 128 * 128 + fo_bytes;
                     const bool wide = l.n % 256 == 0 && lds256 <= cap && a_bytes + (size_t)2 * 256 * 128 >= (size_t)256 * 264 * 2 &&
                                       !getenv("YOLO2_F16_NO_WIDE");
-                    const bool fits = g.Wp + 1 <= kLead && (wide || (lds128 <= cap && a_bytes >= (size_t)256 * kCtRow * 2));
+                    const bool three = lds128 <= cap;
+                    // (the two-buffer 256x128 form that would fit the 104x104 layers runs one workgroup per CU and measured
+                    //  6 % slower there than the 128x128 kernel with two: only the shapes below are used)
+                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three) && lds128s <= 2 * cap;
                     if (fits) {
                         static bool attr_set = false;
                         if (!attr_set) {
                             HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)cap), YOLO2_ERROR);
                             HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)cap), YOLO2_ERROR);
+                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)cap), YOLO2_ERROR);
                             attr_set = true;
                         }
@@ -1716,7 +1727,8 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                             hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
                         } else {
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
-                            hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);
+                            if (three) hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);
+                            else hipLaunchKernelGGL((k_conv_f16_halo<128, 2>), hgrid, dim3(512), lds128s, st, ip, wp, bp, op, a, lt_rows);
                         }
                         if (i != 30) cur = &c->h_out[i];
                         ord++;
