@@ -473,6 +473,33 @@ def test_fp16_mfma_path_vs_fp32_reference():
     ctx.close()
 
 
+@pytest.mark.parametrize("env", ["YOLO2_F16_NO_HALO", "YOLO2_F16_NO_WIDE", "YOLO2_F16_NO_MFMA0", "YOLO2_F16_NO_GLDS"])
+def test_fp16_kernel_variants_agree(env, monkeypatch):
+    """Every fp16 conv kernel family against the fp32 oracle on a ragged batch (5 frames: partial
+    256-pixel tiles on every layer), and against the default selection: the halo-tile kernel vs the
+    per-tap kernels, its 256- vs 128-channel tile, layers 0+1 on MFMA vs fp32 VALU, LDS-DMA vs
+    register staging.  Different summation orders: tolerance, not equality."""
+    model = synth.SynthModel(seed=1)
+    frames = synth.frames(40, 5)
+    orclib.oracle().orc_set_threads(16)
+    refs = [orclib.forward_f32(model, frames[k]).reshape(425, 13, 13) for k in (0, 4)]
+    outs = {}
+    for variant in (None, env):
+        if variant is None:
+            monkeypatch.delenv(env, raising=False)
+        else:
+            monkeypatch.setenv(variant, "1")
+        ctx = hipdrv.Yolo2Hip(0)
+        ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+        outs[variant] = ctx.run_batch_fp16_host(frames)
+        ctx.close()
+        for k, ref in zip((0, 4), refs):
+            assert np.abs(outs[variant][k] - ref).max() <= 0.03, (variant, k)
+    assert np.abs(outs[None] - outs[env]).max() <= 0.02
+    if env != "YOLO2_F16_NO_WIDE":      # (the two halo tile widths sum in the same order)
+        assert not np.array_equal(outs[None], outs[env]), "the toggle did not change the kernel selection"
+
+
 def test_fp16_path_errors():
     ctx = hipdrv.Yolo2Hip(0)
     with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):
