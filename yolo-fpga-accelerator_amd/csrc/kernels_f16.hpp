@@ -13,12 +13,15 @@
 //   M = real pixels (b,y,x),  N = output channels,  K = taps x Cp  (tap-major, channel-minor)
 //   A[m][k] = act[f(m) + tapoff][c]   (64 contiguous bytes per pixel per 32-channel K-step)
 //   B[k][n] = wh[n][tap][c]           (K-contiguous per output channel)
-// Block tile BM pixels x BN channels, one wavefront per 64x64 (2x2 MFMA tiles, 64 fp32 accumulators
-// per lane): 128x128 (4 wavefronts, two workgroups per CU) or 128x64 for <= 64-channel layers;
-// K-step 64 (32 where the item size is 32).  The template also builds 256x128 with 8 wavefronts;
-// measured 8 % slower, so it is not launched.  A and B K-step tiles are staged in
-// LDS (rows padded from 64 to 80 bytes: conflict-free ds_read_b128 fragments), double-buffered,
-// with the global loads of step k+1 in flight while step k is multiplied.
+// Kernel family (yolo2_hip_run_batch_fp16 picks per layer):
+//   k_conv0_pool_mfma   layers 0+1: 3->32 conv + leaky + 2x2 pool straight from the float frames, im2col
+//                       GEMM with K padded 27->32 (k_conv0_pool_f16 is the fp32-VALU form of the same)
+//   k_conv_f16<..,32>   register-staged, K-step 32: the one layer whose items are 32 channels (layer 2)
+//   k_conv_f16_glds     LDS-DMA staging per (tap, 64-channel chunk): 1x1 layers and the 104x104 3x3 layers
+//   k_conv_f16_halo     3x3 layers at <= 52x52: input tile staged once per chunk with its halo, nine taps
+//                       read it shifted; 256 x 256 (or 128) tiles, 8 wavefronts
+// All use 32x32x16 MFMA tiles, one wavefront per 64x64 (or 128x64) of the output, double-buffered LDS
+// stages and an epilogue that transposes through LDS into 16-byte stores.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
@@ -714,36 +717,6 @@ __global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restri
 
 // ------------------------------------------------------------------ small fp16 kernels
 
-// float [B][3][416][416] -> layer-0 im2col items: 27 taps x channels (k = c*9 + i*3 + j), padded to 32
-__global__ void k_pack_input_f16(const float *__restrict__ frames, _Float16 *__restrict__ out, int B, int H, int W,
-                                 int Wp, int PL)
-{
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    const int HW = H * W;
-    if (q >= B * HW) return;
-    const int b = q / HW, r = q - b * HW, y = r / W, x = r - y * W;
-    _Float16 v[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) v[k] = (_Float16)0.f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int sy = y + i - 1, sx = x + j - 1;
-                if (sy >= 0 && sy < H && sx >= 0 && sx < W) v[c * 9 + i * 3 + j] = (_Float16)frames[((size_t)b * 3 + c) * HW + (size_t)sy * W + sx];
-            }
-    half8_t *dst = reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * PL + (size_t)(y + 1) * Wp + x) * 32);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        half8_t o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = v[k * 8 + e];
-        dst[k] = o;
-    }
-}
-
 // 2x2/2 max pool on items, one thread per (output pixel, 8-channel chunk)
 __global__ void k_maxpool2_f16(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int Cp, int B, int OH, int OW,
                                int iWp, int iPL, int oWp, int oPL)
@@ -779,7 +752,7 @@ __global__ void k_reorg_f16(const _Float16 *__restrict__ in, _Float16 *__restric
 }
 
 // weights_reorg (fp32 stream of one layer) -> wh[N_pad][KK][Cp] halves (zero padded).
-// im2col_first: layer 0 is run as a 1x1 conv over k = c*9 + tap (see k_pack_input_f16).
+// im2col_first: pack layer 0 as a 1x1 conv over k = c*9 + tap (kept for experiments; the pass uses w0f).
 __global__ void k_pack_weights_f16(const float *__restrict__ src, _Float16 *__restrict__ dst, float *__restrict__ bias_dst,
                                    const float *__restrict__ bias_src, int C, int N, int KK, int Cp, int Npad, int im2col_first)
 {
