@@ -46,6 +46,11 @@ struct ConvF16Args {
     int leaky;
     int KS;                // 1 or 3
     int n_tiles;           // output-channel tiles per pixel tile (grid = pixel tiles x n_tiles, 1-D)
+    // fused 2x2/2 max pool (conv layers whose only consumer is a pool layer): the tile's MFMA rows are
+    // ordered row = 4*pooled_pixel + 2*dy + dx, the epilogue stores max over each group of four rows
+    // to the POOLED tensor (geometry below) and the full-resolution tensor is never written
+    int pool;              // 0 / 1
+    int oWp, oPL, npool;   // pooled tensor: row pitch, plane size (items), B * (H/2) * (W/2)
 };
 
 constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
@@ -58,6 +63,38 @@ __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
     const int y = r / W;
     const int x = r - y * W;
     return b * PL + (y + 1) * Wp + x;
+}
+
+// flat item offset of MFMA row m of pixel tile `tile` (BM rows per tile)
+__device__ __forceinline__ int tile_row_flat(const ConvF16Args &a, int tile, int BM, int m)
+{
+    const int HW = a.H * a.W;
+    if (!a.pool) return flat_of_h(min(tile * BM + m, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    const int OW = a.W / 2, OHW = (a.H / 2) * OW;
+    const int pq = min(tile * (BM / 4) + (m >> 2), a.npool - 1);
+    const int b = pq / OHW, r = pq - b * OHW, oy = r / OW, ox = r - oy * OW;
+    return b * a.PL + (2 * oy + ((m >> 1) & 1) + 1) * a.Wp + 2 * ox + (m & 1);
+}
+
+// pooled epilogue: Ct holds the BM x BN tile (bias + leaky applied); store max over rows 4p..4p+3
+template <int BM, int BN, int NT, int CTROW>
+__device__ __forceinline__ void store_pooled(const _Float16 (*Ct)[CTROW], _Float16 *__restrict__ out, const ConvF16Args &a, int tile,
+                                             int n0, int tid)
+{
+    constexpr int CH = BN / 8, RPP = NT / CH, PR = BM / 4;
+    const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
+    if (ch0 >= a.n_store) return;
+    const int OW = a.W / 2, OHW = (a.H / 2) * OW;
+#pragma unroll
+    for (int rr = 0; rr < (PR + RPP - 1) / RPP; ++rr) {
+        const int p = r0 + rr * RPP, pq = tile * PR + p;
+        if (p >= PR || pq >= a.npool) continue;
+        half8_t v = *reinterpret_cast<const half8_t *>(&Ct[4 * p][chunk * 8]);
+#pragma unroll
+        for (int k = 1; k < 4; ++k) v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(&Ct[4 * p + k][chunk * 8]));
+        const int b = pq / OHW, r = pq - b * OHW, oy = r / OW, ox = r - oy * OW;
+        *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + ox) * a.Cp_out + a.out_ch_off + ch0) = v;
+    }
 }
 
 // act: items of Cp_in halves (pointer at item 0 incl. lead); wh: [N_pad][KK][Cp_in] halves;
@@ -95,7 +132,8 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) 
     const int n0 = (blockIdx.x % a.n_tiles) * BN;
     const int KK = a.KS * a.KS;
 
-    for (int i = tid; i < kBM; i += NT) fo_s[i] = flat_of_h(min(q0 + i, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    const int tile = blockIdx.x / a.n_tiles;
+    for (int i = tid; i < kBM; i += NT) fo_s[i] = tile_row_flat(a, tile, kBM, i);
     __syncthreads();
 
     // staging map: thread -> (row, 16-byte chunk), APASS / BPASS rows per thread
@@ -224,6 +262,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) 
             }
     }
     __syncthreads();
+    if (a.pool) {
+        store_pooled<kBM, BN, NT, kCtRow>(Ct, out, a, tile, n0, tid);
+        return;
+    }
     constexpr int CH = BN / 8;               // 16-byte chunks per pixel row
     constexpr int ROWS_PER_PASS = NT / CH;
     const int chunk = tid % CH, r0 = tid / CH;
@@ -276,7 +318,8 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
     const int n0 = (blockIdx.x % a.n_tiles) * BN;
     const int KK = a.KS * a.KS;
 
-    if (tid < BM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    const int tile = blockIdx.x / a.n_tiles;
+    if (tid < BM) fo_s[tid] = tile_row_flat(a, tile, BM, tid);
     __syncthreads();
 
     // fill map: wave-instruction i covers rows R0 = (wave*G + i)*8 .. +7; lane -> (row, LDS slot); source chunk = slot ^ swz(row)
@@ -394,6 +437,10 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
             }
     }
     __syncthreads();
+    if (a.pool) {
+        store_pooled<BM, BN, 256, kCtRow>(Ct, out, a, tile, n0, tid);
+        return;
+    }
     constexpr int CH = BN / 8, ROWS_PER_PASS = 256 / CH;
     const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
     if (ch0 < a.n_store) {

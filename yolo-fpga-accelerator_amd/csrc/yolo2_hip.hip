@@ -1663,7 +1663,7 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                                416, 416, g.Wp, g.PL);
         if (ev) { (void)hipEventRecord(ev[1], st); (void)hipEventRecord(ev[2], st); }
     }
-    int ord = 1;
+    int ord = 1, skip_pool = -1;
     const yolo2_hip_ctx::HalfTensor *cur = &c->h_out[1];
     for (int i = 2; i < 32; ++i) {
         const LayerDesc &l = kNet[i];
@@ -1681,6 +1681,7 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             a.npix = B * l.h * l.w;
             a.leaky = l.leaky;
             a.KS = l.size;
+            a.pool = 0; a.oWp = a.oPL = a.npool = 0;
             const _Float16 *wp = (const _Float16 *)(c->wh + c->wh_off[ord]);
             const float *bp = (const float *)(c->biasf + c->biasf_off[ord]);
             _Float16 *op = i == 30 ? (_Float16 *)nullptr : tout.d;
@@ -1688,9 +1689,20 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             const bool bk64 = a.Cp_in % 64 == 0;   // K-step of 64 channels wherever the item size allows it
             const _Float16 *ip = (const _Float16 *)tin->d;
             const bool glds = bk64 && !getenv("YOLO2_F16_NO_GLDS");   // LDS-DMA staging wherever the K-step is 64
+            // Conv layers whose only consumer is the 2x2 pool after them (2 and 6; 10 runs the halo kernel, 16 also
+            // feeds the route) store the pooled tensor directly: MFMA rows ordered by pool window, max in the epilogue.
+            const bool fuse_pool = (i == 2 || i == 6) && kNet[i + 1].type == L_MAX && !getenv("YOLO2_F16_NO_POOLFUSE");
+            if (fuse_pool) {
+                const auto &tp = c->h_out[i + 1];
+                a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
+                a.Cp_out = tp.Cp;
+                op = tp.d;
+                skip_pool = i + 1;
+            }
+            const int m_tiles = fuse_pool ? (a.npool + 31) / 32 : (a.npix + 127) / 128;   // 128-row tiles (32 pool windows)
             if (l.n <= 64) {
                 a.n_tiles = round_up(l.n, 64) / 64;
-                const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
+                const dim3 grid(m_tiles * a.n_tiles);
                 if (glds) hipLaunchKernelGGL((k_conv_f16_glds<64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 64, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else hipLaunchKernelGGL((k_conv_f16<128, 64, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
@@ -1737,16 +1749,17 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                 }
                 // (a 256x128 tile with 8 wavefronts and per-tap A staging was measured 8 % SLOWER than 128x128
                 //  with two workgroups per CU: without the halo reuse the bigger tile only adds barrier cost)
-                const dim3 grid(((a.npix + 127) / 128) * a.n_tiles);
+                const dim3 grid(m_tiles * a.n_tiles);
                 if (glds) hipLaunchKernelGGL((k_conv_f16_glds<128>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else if (bk64) hipLaunchKernelGGL((k_conv_f16<128, 128, 64>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
                 else hipLaunchKernelGGL((k_conv_f16<128, 128, 32>), grid, dim3(256), 0, st, ip, wp, bp, op, of, a);
             }
-            if (i != 30) cur = &c->h_out[i];
+            if (i != 30) cur = fuse_pool ? &c->h_out[i + 1] : &c->h_out[i];
             ord++;
             break;
         }
         case L_MAX: {
+            if (i == skip_pool) break;   // already produced by the conv before it
             const auto &gi = *cur, &go = c->h_out[i];
             const long n = (long)B * go.H * go.W * (go.Cp / 8);
             hipLaunchKernelGGL(k_maxpool2_f16, dim3(blocks_for(n, 256)), dim3(256), 0, st, (const _Float16 *)gi.d, go.d, go.Cp, B,
