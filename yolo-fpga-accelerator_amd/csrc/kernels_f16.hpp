@@ -469,19 +469,20 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
 // straddled an image-row end its rows skipped one and 39 % of the LDS cycles were bank conflicts.)
 // A dense tile has no zeros for out-of-image taps, so a lane whose tap leaves the image reads a
 // dedicated all-zero row instead (one v_cndmask on the address; identical addresses broadcast).
-template <int BN, int NB>
-__global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+template <int BN, int NB, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                         const ConvF16Args a, const int lt_rows)
 {
-    constexpr int BM = 256, BK = 64, ROWH = BK, NW = 8;
+    constexpr int BM = 256, BK = 64, ROWH = BK, NT = NW * 64;
     // BN = 128: 4 x 2 wavefronts of 64 x 64, NB = 3 weight-tile buffers;
-    // BN = 256: 2 x 4 wavefronts of 128 x 64 (twice the MFMAs per barrier and per A-fragment read), NB = 2
+    // BN = 256: 2 x 4 wavefronts of 128 x 64 (NW = 8) or 4 x 4 of 64 x 64 (NW = 16: four wavefronts per SIMD fill the
+    //           bubbles around the per-tap barrier better, +4 %), NB = 2
     constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / 32;
     constexpr int BG = BN / 8 / NW;                                // B fill instructions per wavefront and tap
     constexpr int kCt = BN + 8;                                    // halves per row of the epilogue staging tile
-    constexpr int kMaxAIters = 8;                                  // A fill instructions per wavefront (host: lt_rows <= 8*8*8 + 8)
-    static_assert((MT == 2 || MT == 4) && BG >= 1 && (NB == 2 || NB == 3), "tile shape");
+    constexpr int kMaxAIters = 64 / NW;                            // A fill instructions per wavefront (host: lt_rows <= 64*8 + 8)
+    static_assert((MT == 2 || MT == 4) && BG >= 1 && (NB == 2 || NB == 3) && (NW == 8 || NW == 16), "tile shape");
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
     _Float16 *As = smem_h;                                   // [2][lt_rows][64]; rows lt_rows-8.. of each buffer stay zero
     _Float16 *Bs = smem_h + (size_t)2 * lt_rows * ROWH;      // [NB][BN][64]: with NB = 3 the weight tile of tap t+2 is in flight while t is multiplied
@@ -631,8 +632,8 @@ __global__ __launch_bounds__(512) void k_conv_f16_halo(const _Float16 *__restric
 
     // epilogue: bias + leaky, transposed through LDS into 16-byte stores (the staging arena is free now)
     _Float16 (*Ct)[kCt] = reinterpret_cast<_Float16 (*)[kCt]>(smem_h);
-    int fo_r[BM / (512 / (BN / 8))];   // fo_s lives behind the arena the Ct tile may overlap: keep what this thread needs
-    constexpr int CH = BN / 8, ROWS_PER_PASS = 512 / CH;
+    int fo_r[BM / (NT / (BN / 8))];   // fo_s lives behind the arena the Ct tile may overlap: keep what this thread needs
+    constexpr int CH = BN / 8, ROWS_PER_PASS = NT / CH;
     const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
 #pragma unroll
     for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) fo_r[rr] = fo_s[r0 + rr * ROWS_PER_PASS];

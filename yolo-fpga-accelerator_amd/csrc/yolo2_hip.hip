@@ -1731,12 +1731,17 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                                                         (int)cap), YOLO2_ERROR);
                             HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                         (int)cap), YOLO2_ERROR);
+                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)cap), YOLO2_ERROR);
                             attr_set = true;
                         }
                         if (wide) {
                             a.n_tiles = l.n / 256;
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
-                            hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
+                            if (!getenv("YOLO2_F16_W8"))   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
+                                hipLaunchKernelGGL((k_conv_f16_halo<256, 2, 16>), hgrid, dim3(1024), lds256, st, ip, wp, bp, op, a, lt_rows);
+                            else
+                                hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
                         } else {
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
                             if (three) hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);
