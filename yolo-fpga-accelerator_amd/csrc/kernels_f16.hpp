@@ -861,19 +861,32 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
         }
     const float bv = bias0[n];
 
-    // stage the patch: rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32, zero outside the image
+    // stage the patch: rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32, zero outside the image.  All of a
+    // thread's loads are issued before the first conversion (clamped addresses, masked afterwards).
     const float *fb = frames + (size_t)b * 3 * H * W;
-    for (int i = tid; i < 3 * PR * PC; i += 256) {
-        const int c = i / (PR * PC), r = i - c * (PR * PC), py = r / PC, px = r - py * PC;
+    constexpr int NEL = 3 * PR * PC, NIT = (NEL + 255) / 256;
+    float pv[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = min(tid + it * 256, NEL - 1);
+        const int c = i / (PR * PC), r2 = i - c * (PR * PC), py = r2 / PC, px = r2 - py * PC;
         const int sy = ty0 + py - 1, sx = tx0 + px - 1;
-        const float v = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? fb[((size_t)c * H + sy) * W + sx] : 0.f;
-        patch[(c * PR + py) * PCS + px] = (_Float16)v;
+        pv[it] = fb[((size_t)c * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)];
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        if (i < NEL) {
+            const int c = i / (PR * PC), r2 = i - c * (PR * PC), py = r2 / PC, px = r2 - py * PC;
+            const int sy = ty0 + py - 1, sx = tx0 + px - 1;
+            patch[(c * PR + py) * PCS + px] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? (_Float16)pv[it] : (_Float16)0.f;
+        }
     }
     __syncthreads();
 
     // this lane's pixel inside an MFMA block: row r = 4*pc + 2*dy + dx
     const int r = lane & 31, dx = r & 1, dy = (r >> 1) & 1, pc = r >> 2;
-    const int oW = W / 2;
+    __shared__ __attribute__((aligned(16))) _Float16 otile[8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
 #pragma unroll
     for (int mb = 0; mb < 4; ++mb) {
         const int prow = wave * 2 + (mb >> 1), chalf = mb & 1;            // pooled row 0..7, column half 0..1 of the tile
@@ -889,16 +902,22 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[kk], acc, 0, 0, 0);
         }
         // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
-        const int oy = ty0 / 2 + prow;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
             if (v < 0.f) v *= 0.1f;
-            const int ox = tx0 / 2 + chalf * 8 + 2 * g + h;
-            out[((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + n] = (_Float16)v;
+            otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
         }
     }
-    (void)oW;
+    __syncthreads();
+    // 128 pooled pixels x 4 chunks of 8 channels = 512 16-byte stores, two per thread
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = tid + it * 256, pp = e >> 2, ck = e & 3;
+        const int oy = ty0 / 2 + (pp >> 4), ox = tx0 / 2 + (pp & 15);
+        *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + ck * 8) =
+            *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
+    }
 }
 
 // layer-0 weights for k_conv0_pool_f16: weights_reorg fp32 (C=3, N=32, 3x3) -> w0[k = c*9 + tap][n]
