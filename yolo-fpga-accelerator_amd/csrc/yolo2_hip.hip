@@ -1167,7 +1167,9 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
     if (!c->weights_loaded) return fail(YOLO2_ERROR, "load weights before set_batch");
     HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
-    const bool want_lanes = !c->is_lane && batch >= 16 && batch % 2 == 0 && !getenv("YOLO2_NO_LANES");
+    int nl = 2;   // YOLO2_LANES=n: experiment hook (default two lanes)
+    if (const char *e = getenv("YOLO2_LANES")) nl = std::max(1, atoi(e));
+    const bool want_lanes = !c->is_lane && nl > 1 && batch >= 8 * nl && batch % nl == 0 && !getenv("YOLO2_NO_LANES");
     if (!want_lanes) {
         destroy_lanes(c);
         return set_batch_single(c, batch);
@@ -1176,12 +1178,12 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     destroy_lanes(c);
     free_activations(c);
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < nl; ++i) {
         yolo2_hip_ctx *l = nullptr;
         int rc = make_lane(c, &l);
         if (rc == YOLO2_SUCCESS) {
             c->lanes.push_back(l);
-            rc = set_batch_single(l, batch / 2);
+            rc = set_batch_single(l, batch / nl);
         }
         if (rc) { destroy_lanes(c); return rc; }
     }
@@ -1237,7 +1239,7 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
     return YOLO2_SUCCESS;
 }
 
-extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? 2 : 1; }
+extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? (int)c->lanes.size() : 1; }
 
 extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
 {
@@ -1307,9 +1309,9 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
     }
     hipStream_t st = (hipStream_t)stream;
     if (c->laned) {   // fork the two half-batches onto the lane streams, join back into the caller's stream
-        const int half = batch / 2;
+        const int nl = (int)c->lanes.size(), half = batch / nl;
         HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < nl; ++i) {
             yolo2_hip_ctx *l = c->lanes[i];
             HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
             const int rc = yolo2_hip_run_batch_int16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
@@ -1407,7 +1409,7 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
     if (!c || !out) return fail(YOLO2_ERROR, "null argument");
     if (layer_idx < 0 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
     if (c->laned) {
-        const int half = c->batch / 2;
+        const int half = c->batch / (int)c->lanes.size();
         return yolo2_hip_debug_layer_output(c->lanes[frame / half], layer_idx, frame % half, out, cap, out_elems);
     }
     const LayerDesc &l = kNet[layer_idx];
