@@ -71,6 +71,11 @@ int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int c
                                 int padding, int tm, int tr, int tc, int ofm_num_bound, int mloopsxTM,
                                 int mloops_a1xTM, uint32_t timeout_ms);
 
+/* Arithmetic form the most recent yolo2_execute_conv_layer ran (codes of yolo2_hip_layer_path below;
+ * -1 = the generic one-thread-per-output kernel for shapes the tiled kernel does not cover).  The
+ * per-layer calls prove the form for the whole layer from the weights and Q values of that call. */
+int yolo2_hip_last_layer_path(void);
+
 /* fp32 twin of the conv call (host-sim form YOLO2_FPGA without INT16_MODE,
  * hls/models/yolov2/yolo2_accel.hpp:10-17): float tensors, Q arguments absent. */
 int yolo2_execute_conv_layer_f32(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,

@@ -46,7 +46,7 @@ def force_path(monkeypatch):
 
 # ------------------------------------------------------------------ per-layer driver calls
 
-@pytest.mark.parametrize("path", [None, 0, 1, 2, 3])
+@pytest.mark.parametrize("path", [None, 0, 1, 2, 3, 4])
 @pytest.mark.parametrize("name", [str(n) for n in KAT["conv_i16/names"]])
 def test_conv_i16_kat_bit_exact(name, path, force_path):
     """Every known-answer conv case, through the tiled kernel's three arithmetic paths
@@ -107,6 +107,29 @@ def test_random_conv_vs_oracle(seed, force_path):
         force_path(path)
         got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, 1, W, H, pad, leaky, Qw, Qai, Qao, Qb)
         assert np.array_equal(got, want), (seed, path)
+
+
+@pytest.mark.parametrize("K,s_shift", [(3, 14), (1, 14), (3, 16), (3, 9), (1, 5)])
+def test_conv_form_d_through_driver(K, s_shift, driver):
+    """Form D (shift folded into pre-scaled weights) through the per-layer call: weights with
+    16 - s bits of int16 headroom, full-range activations and biases so that the accumulator
+    saturates both ways; the driver must pick form D on its own and match the oracle bit for bit."""
+    rng = np.random.default_rng(900 + 10 * K + s_shift)
+    C, N, W, H = 37, 70, 29, 17
+    Qai, Qao = 9, 9
+    Qw = s_shift + Qao - Qai            # s = Qa_in + Qw - Qa_out
+    wmax = min(32767 >> (16 - s_shift), (1 << s_shift) // 5)      # headroom for w * 2^(16-s) and for sum(|w|) of 4 channels
+    x = np.zeros((C, H, orclib.w8(W)), dtype=np.int16)
+    x[:, :, :W] = rng.integers(-32768, 32768, (C, H, W))
+    w = rng.integers(-wmax, wmax + 1, (N, C, K, K)).astype(np.int16)
+    b = rng.integers(-32767, 32768, N).astype(np.int16)      # (a bias of -32768 does not fit a packed int16 accumulator)
+    wr = synth.reorg_weights(w, C, N, K)
+    pad = 1 if K == 3 else 0
+    want = orclib.conv_i16(x, wr, b, C, N, K, 1, W, H, pad, 1, Qw, Qai, Qao, 9)
+    got = hipdrv.conv_layer_i16(x, wr, b, C, N, K, 1, W, H, pad, 1, Qw, Qai, Qao, 9)
+    assert driver.yolo2_hip_last_layer_path() == 4
+    assert np.array_equal(got, want)
+    assert (want == 32767).any() and (want <= -3276).any()      # the chain really saturated (leaky: -32768 -> -3276)
 
 
 def test_driver_error_codes(driver):

@@ -301,6 +301,7 @@ struct DriverState {
     int qw = 0, qa_in = 0, qa_out = 0, qb = 0;
     // grow-only scratch for the per-layer calls
     void *in_items = nullptr, *out_items = nullptr, *wpk = nullptr, *bias_pk = nullptr;
+    int last_path = -1;   // arithmetic form of the most recent yolo2_execute_conv_layer (-1: generic reference-layout kernel)
     size_t in_cap = 0, out_cap = 0, wpk_cap = 0, bias_cap = 0;
     int *bound = nullptr;
     struct HostBuf {
@@ -379,7 +380,7 @@ extern "C" int yolo2_accel_init(void)
     if (yolo2_hip_device_count() <= g_drv.device)
         return fail(YOLO2_INIT_ERROR, "no HIP device available (the GPU path has no CPU fallback)");
     HIP_TRY(hipSetDevice(g_drv.device), YOLO2_INIT_ERROR);
-    if (!g_drv.bound) HIP_TRY(hipMalloc((void **)&g_drv.bound, sizeof(int)), YOLO2_MMAP_ERROR);
+    if (!g_drv.bound) HIP_TRY(hipMalloc((void **)&g_drv.bound, 4 * sizeof(int)), YOLO2_MMAP_ERROR);   // [max sum, max sum (1 block), max |w|, scale byte]
     g_drv.inited = true;
     return YOLO2_SUCCESS;
 }
@@ -520,6 +521,7 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
         if (tile_items_bound(g, 64, ksize == 3 ? g.Wp + 1 : 0) > kMaxTileItems) tiled = false;
     }
     if (!tiled) {
+        g_drv.last_path = -1;
         const int n = ofm_num * output_h * output_w;
         hipLaunchKernelGGL(k_conv_ref_i16, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, w, beta, ifm_num, ofm_num,
                            ksize, kstride, input_w, input_h, output_w, output_h, padding, is_nl ? 1 : 0, so, sb);
@@ -545,16 +547,26 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
                        ifm_num, ofm_num, ksize * ksize);
     hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(wpk_elems / 4, 256), 1024)), dim3(256), 0, st,
                        (const short *)g_drv.wpk, wpk_elems / 4, g_drv.bound);
-    int maxsum = 0, maxb = 0;
-    HIP_TRY(hipMemcpy(&maxsum, g_drv.bound, sizeof(int), hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    // whole layer as one "block": its largest |w| decides whether the shift can be folded into the weights (form D)
+    hipLaunchKernelGGL(k_weight_bound_mb, dim3(1), dim3(256), 0, st, (const short *)g_drv.wpk, wpk_elems / 4, g_drv.bound + 1,
+                       g_drv.bound + 2);
+    int hbound[3] = {0, 0, 0}, maxb = 0;
+    HIP_TRY(hipMemcpy(hbound, g_drv.bound, sizeof(hbound), hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    const int maxsum = hbound[0], maxabs = hbound[2];
     if ((rc = max_abs_i16_dev(beta, ofm_num, &maxb))) return rc;
 
     ConvPlan p;
     p.args.mb_list = nullptr;
     p.C = ifm_num; p.N = ofm_num; p.K = ksize; p.H = input_h; p.W = input_w; p.leaky = is_nl ? 1 : 0;
     p.Qw = qw; p.Qa_in = qa_in; p.Qa_out = qa_out; p.Qb = qb;
-    p.path = choose_path(so, sb, maxsum, maxb);
+    p.path = choose_path(so, sb, maxsum, maxb, maxabs);
+    if (p.path == 4) {   // this call's packed copy carries w * 2^(16-s)
+        HIP_TRY(hipMemsetAsync(g_drv.bound + 3, 16 - so, 1, st), YOLO2_DMA_ERROR);
+        hipLaunchKernelGGL(k_scale_weight_blocks, dim3(std::min<unsigned>(blocks_for(wpk_elems, 256), 256), 1), dim3(256), 0, st,
+                           (short *)g_drv.wpk, wpk_elems, (const signed char *)(g_drv.bound + 3));
+    }
     plan_conv(p, gi, go.cg_stride, kLead, go.CG);
+    g_drv.last_path = p.path;
     launch_conv(p, (const int2 *)g_drv.in_items, (int2 *)g_drv.out_items, (const int2 *)g_drv.wpk, (const short *)g_drv.bias_pk, st);
     hipLaunchKernelGGL(k_items_to_ref, dim3(blocks_for((long)ofm_num * output_h * output_w, 256)), dim3(256), 0, st,
                        (const short *)g_drv.out_items, out, ofm_num, output_h, output_w, (output_w + 7) & ~7, go.Wp, go.PL,
@@ -562,6 +574,8 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
     return sync_with_timeout(st, timeout_ms);
 }
+
+extern "C" int yolo2_hip_last_layer_path(void) { return g_drv.last_path; }
 
 extern "C" int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int channels, int ksize,
                                            int kstride, int input_w, int input_h, int output_w, int output_h,

@@ -30,7 +30,7 @@ EXPORTS = [
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
-    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host",
+    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path",
 ]
 
 
