@@ -208,6 +208,15 @@ int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x, int *grid_y,
                                int *block, int *lds_bytes, int *pixels_per_lane);
 
+/* fp32 whole network in the reference's own arithmetic (what yolov2_hls_ps does at Precision::FP32,
+ * hls/models/yolov2/yolo2_model.cpp:229-449: compute() fp32 branch core_compute.cpp:121-172 in its
+ * operation order without FMA contraction, pool_yolo2, the legacy reorg): one frame
+ * float [3][416][416] on the host -> float [425][13][13] on the host, bit-identical to the
+ * reference's region tensor, hence identical boxes (BASELINE.json asks for 1e-3).  A correctness
+ * path built from the one-thread-per-output kernels; the fast floating-point path is
+ * yolo2_hip_run_batch_fp16.  Needs yolo2_hip_load_weights_fp32. */
+int yolo2_hip_run_frame_fp32_host(yolo2_hip_ctx *ctx, const float *frame, float *region);
+
 /* GPU pre-processing (the step before the path): the reference host's
  * load_image_stb (bytes / 255.f, src/core/yolo_image.cpp:29-63) + letterbox_image (two-pass bilinear
  * resize_image onto a 0.5 canvas, src/core/yolo_image.cpp:84-165) as one kernel, float-for-float in

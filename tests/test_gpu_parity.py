@@ -523,6 +523,25 @@ def test_fp16_kernel_variants_agree(env, monkeypatch):
         assert not np.array_equal(outs[None], outs[env]), "the toggle did not change the kernel selection"
 
 
+def test_fp32_whole_network_bit_exact_vs_reference_fixture():
+    """The exact fp32 pass (reference operation order, no contraction) against the fp32 region tensor
+    the compiled reference produced: bit for bit, so the boxes are identical (BASELINE.json: 1e-3)."""
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]))
+    frame = synth.frames(int(FULL["meta/frame_seed"]), 1)[0]
+    ctx = hipdrv.Yolo2Hip(0)
+    with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):
+        ctx.run_frame_fp32_host(frame)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    got = ctx.run_frame_fp32_host(frame)
+    want = FULL["f32/std/region_raw_f32"].reshape(425, 13, 13)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), np.abs(got - want).max()
+    # a second, different frame against the oracle
+    f2 = synth.frames(99, 1)[0]
+    orclib.oracle().orc_set_threads(16)
+    assert np.array_equal(ctx.run_frame_fp32_host(f2).reshape(-1).view(np.uint32), orclib.forward_f32(model, f2).view(np.uint32))
+    ctx.close()
+
+
 def test_fp16_path_errors():
     ctx = hipdrv.Yolo2Hip(0)
     with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):

@@ -672,6 +672,7 @@ struct yolo2_hip_ctx {
     _Float16 *wh = nullptr;
     float *biasf = nullptr;
     float *w0f = nullptr;  // layer 0: [27][32] fp32 weights + [32] bias for the fused conv0+pool kernel
+    float *wf32 = nullptr, *bf32 = nullptr;   // the fp32 blobs as loaded (reference stream order), for the exact fp32 pass
     long wh_off[YOLO2_N_CONV], biasf_off[YOLO2_N_CONV];
     int f16_batch = 0;
     HalfTensor h_in, h_out[32], h_cat;
@@ -794,6 +795,8 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
     if (c->wh) (void)hipFree(c->wh);
     if (c->biasf) (void)hipFree(c->biasf);
     if (c->w0f) (void)hipFree(c->w0f);
+    if (c->wf32) (void)hipFree(c->wf32);
+    if (c->bf32) (void)hipFree(c->bf32);
     if (c->wpk) (void)hipFree(c->wpk);
     if (c->bias_pk) (void)hipFree(c->bias_pk);
     if (c->mb_lists) (void)hipFree(c->mb_lists);
@@ -1619,10 +1622,109 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
     hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
     HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
-    (void)hipFree(wd);
-    (void)hipFree(bd);
+    // the fp32 blobs stay resident (204 MB of 288 GB): yolo2_hip_run_frame_fp32_host consumes them as they are
+    if (c->wf32) (void)hipFree(c->wf32);
+    if (c->bf32) (void)hipFree(c->bf32);
+    c->wf32 = wd;
+    c->bf32 = bd;
     c->f16_loaded = true;
     return YOLO2_SUCCESS;
+}
+
+// fp32 whole network, reference arithmetic: every layer in the reference's [C][H][W8] layout through the
+// one-thread-per-output kernels (k_conv_ref_f32: reference operation order, no FMA contraction; k_pool_ref;
+// the legacy reorg indexing of yolo2_model.cpp:112-129,358-376), i.e. what yolov2_hls_ps does at
+// Precision::FP32 (yolo2_model.cpp:229-449).  Bit-identical to the reference's fp32 region tensor; a
+// correctness path (about 0.2 s per frame), not a fast one - the fast floating-point path is run_batch_fp16.
+__global__ void k_reorg_ref_f32(const float *__restrict__ in, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // over 256*13 rows x 13 columns
+    if (t >= 256 * 13 * 13) return;
+    const int kr = t / 13, cc = t - kr * 13;
+    const int p = kr * 13 + cc;                            // index into the permuted dense tensor
+    const int i = p % 26, rest = p / 26, j = rest % 416, k = rest / 416;
+    const int d = (2 * i + k % 2) + 52 * (2 * j + k / 2);  // index into the dense 64 x 26 x 26 input
+    out[(size_t)kr * 16 + cc] = in[(size_t)(d / 26) * 32 + d % 26];
+}
+
+extern "C" int yolo2_hip_run_frame_fp32_host(yolo2_hip_ctx *c, const float *frame, float *region)
+{
+    if (!c || !frame || !region) return fail(YOLO2_ERROR, "null argument");
+    if (!c->f16_loaded || !c->wf32) return fail(YOLO2_ERROR, "fp32 weights not loaded (yolo2_hip_load_weights_fp32)");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    auto w8 = [](int w) { return (w + 7) & ~7; };
+    float *bufs[32] = {nullptr};
+    float *in0 = nullptr, *cat = nullptr;
+    int rc = YOLO2_SUCCESS;
+    auto release = [&]() {
+        (void)hipDeviceSynchronize();
+        for (int i = 0; i < 32; ++i)
+            if (bufs[i] && i != 24 && i != 27) (void)hipFree(bufs[i]);
+        (void)hipFree(in0); (void)hipFree(cat);
+    };
+    auto dalloc = [&](float **p, size_t elems) -> bool {
+        if (hipMalloc((void **)p, elems * sizeof(float)) != hipSuccess || hipMemsetAsync(*p, 0, elems * sizeof(float), nullptr) != hipSuccess) {
+            rc = fail(YOLO2_MMAP_ERROR, "fp32 pass: activation buffer allocation failed");
+            return false;
+        }
+        return true;
+    };
+    if (!dalloc(&in0, (size_t)3 * 416 * 416) || !dalloc(&cat, (size_t)1280 * 13 * 16)) { release(); return rc; }
+    if (hipMemcpyAsync(in0, frame, (size_t)3 * 416 * 416 * sizeof(float), hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+        release();
+        return fail(YOLO2_DMA_ERROR, "H2D of the frame failed");
+    }
+    const float *cur = in0;
+    long woff = 0, boff = 0;
+    int ord = 0;
+    for (int i = 0; i < 32 && rc == YOLO2_SUCCESS; ++i) {
+        const LayerDesc &l = kNet[i];
+        const int pad = l.type == L_CONV ? (l.size == 3 ? 1 : 0) : 0;
+        const int ow = l.type == L_CONV ? (l.w - l.size + 2 * pad) + 1 : l.w / 2, oh = l.type == L_CONV ? (l.h - l.size + 2 * pad) + 1 : l.h / 2;
+        switch (l.type) {
+        case L_CONV: {
+            const float *src = i == 26 ? bufs[16] : (i == 29 ? cat : cur);
+            float *dst = nullptr;
+            if (i == 24) dst = cat + (size_t)256 * 13 * 16;
+            else if (!dalloc(&dst, (size_t)l.n * oh * w8(ow))) break;
+            hipLaunchKernelGGL(k_conv_ref_f32, dim3(blocks_for((long)l.n * oh * ow, 256)), dim3(256), 0, nullptr, src, dst,
+                               (const float *)(c->wf32 + woff), (const float *)(c->bf32 + boff), l.c, l.n, l.size, 1, l.w, l.h, ow, oh,
+                               pad, l.leaky);
+            woff += yolo2_weight_len[ord];
+            boff += yolo2_bias_len[ord];
+            ord++;
+            bufs[i] = dst;
+            cur = dst;
+            break;
+        }
+        case L_MAX: {
+            float *dst = nullptr;
+            if (!dalloc(&dst, (size_t)l.c * oh * w8(ow))) break;
+            hipLaunchKernelGGL((k_pool_ref<float>), dim3(blocks_for((long)l.c * oh * ow, 256)), dim3(256), 0, nullptr, cur, dst, l.c, 2, 2,
+                               l.w, l.h, ow, oh, -1024.f * 1024.f);   // pad value of core_compute.cpp:291, core_io.cpp:101
+            bufs[i] = dst;
+            cur = dst;
+            break;
+        }
+        case L_REORG:
+            hipLaunchKernelGGL(k_reorg_ref_f32, dim3(blocks_for(256 * 13 * 13, 256)), dim3(256), 0, nullptr, cur, cat);
+            bufs[i] = cat;
+            cur = cat;
+            break;
+        default:
+            break;   // route: concat by placement; region: gathered below
+        }
+    }
+    if (rc == YOLO2_SUCCESS && hipGetLastError() != hipSuccess) rc = fail(YOLO2_ERROR, "fp32 pass: kernel launch failed");
+    if (rc == YOLO2_SUCCESS) {   // yolo2_model.cpp:406-414: 13 of 16 columns
+        std::vector<float> padded((size_t)425 * 13 * 16);
+        if (hipMemcpy(padded.data(), cur, padded.size() * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(YOLO2_DMA_ERROR, "D2H of the region tensor failed");
+        else
+            for (int k = 0; k < 425 * 13; ++k) memcpy(region + (size_t)k * 13, padded.data() + (size_t)k * 16, 13 * sizeof(float));
+    }
+    release();
+    return rc;
 }
 
 static int alloc_half(yolo2_hip_ctx::HalfTensor &t, int C, int Cp, int H, int W, int B)

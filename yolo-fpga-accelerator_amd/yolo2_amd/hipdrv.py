@@ -30,7 +30,7 @@ EXPORTS = [
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
-    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path",
+    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path", "yolo2_hip_run_frame_fp32_host",
 ]
 
 
@@ -107,6 +107,7 @@ def lib():
     L.yolo2_hip_load_weights_fp32.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
     L.yolo2_hip_run_batch_fp16.argtypes = [vp, u64, i32, u64, vp]
     L.yolo2_hip_run_batch_fp16_host.argtypes = [vp, vp, i32, vp]
+    L.yolo2_hip_run_frame_fp32_host.argtypes = [vp, vp, vp]
     L.yolo2_hip_letterbox_u8.argtypes = [u64, i32, i32, i32, u64, i32, i32, vp]
     L.yolo2_hip_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.memory_get_phys_addr.restype = u64
@@ -301,6 +302,14 @@ class Yolo2Hip:
         b = np.ascontiguousarray(bias_f32, dtype=np.float32)
         check(lib().yolo2_hip_load_weights_fp32(self._h, w.ctypes.data_as(C.c_void_p), w.size,
                                                 b.ctypes.data_as(C.c_void_p), b.size), "yolo2_hip_load_weights_fp32")
+
+    def run_frame_fp32_host(self, frame: np.ndarray) -> np.ndarray:
+        """One frame through the exact fp32 network (reference arithmetic); needs load_weights_fp32."""
+        f = np.ascontiguousarray(frame, dtype=np.float32).reshape(3, 416, 416)
+        region = np.empty((425, 13, 13), dtype=np.float32)
+        check(lib().yolo2_hip_run_frame_fp32_host(self._h, f.ctypes.data_as(C.c_void_p), region.ctypes.data_as(C.c_void_p)),
+              "yolo2_hip_run_frame_fp32_host")
+        return region
 
     def run_batch_fp16_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0):
         check(lib().yolo2_hip_run_batch_fp16(self._h, frames_ptr, batch, region_ptr, C.c_void_p(stream)),
