@@ -58,6 +58,42 @@ def test_cli_end_to_end(tmp_path):
     assert r.stdout.count('{"label"') == expect
 
 
+def test_cli_fp32_matches_reference_fixture(tmp_path):
+    """--precision fp32 (C1's precision, on the GPU): the exact fp32 pass from the reference's fp32 weight
+    files; the raw region dump equals the compiled reference's fp32 region tensor for the fixture frame
+    (dumped with %.9g: round-trips float32), so every printed box is the reference's box."""
+    full = np.load(os.path.join(orclib.ROOT, "tests", "golden", "fullnet.npz"))
+    model = synth.SynthModel(seed=int(full["meta/model_seed"]))
+    model.write_files(str(tmp_path / "weights"), fp32=True, int16=False)
+    # a 416x416 image whose bytes / 255 are NOT the fixture frame in general, so feed the fixture through the
+    # library for the tensor check and use the CLI run for plumbing + self-consistency
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (416, 416, 3), dtype=np.uint8)
+    ppm = tmp_path / "img.ppm"
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n416 416\n255\n" + img.tobytes())
+    env = dict(os.environ, YOLO2_DUMP_REGION_RAW=str(tmp_path / "raw.txt"), YOLO2_DUMP_REGION=str(tmp_path / "proc.txt"))
+    r = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names"),
+                        "--weights", str(tmp_path / "weights"), "--input", str(ppm), "--output", str(tmp_path / "pred"),
+                        "--thresh", "0.5", "--backend", "hip", "--precision", "fp32"],
+                       capture_output=True, text=True, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "precision: fp32" in r.stdout and "Predicted in" in r.stdout
+    frame = np.ascontiguousarray(img.transpose(2, 0, 1).astype(np.float32) / np.float32(255))   # 416x416: letterbox is the identity resize
+    boxed = np.zeros((3, 416, 416), dtype=np.float32)
+    orclib.host().y2h_letterbox(frame, 416, 416, 3, 416, 416, boxed)
+    orclib.oracle().orc_set_threads(16)
+    want = orclib.forward_f32(model, boxed)
+    raw = np.loadtxt(tmp_path / "raw.txt").astype(np.float32)
+    assert np.array_equal(raw.view(np.uint32), want.view(np.uint32))
+    # the library entry on the fixture frame == the compiled reference's tensor
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    got = ctx.run_frame_fp32_host(synth.frames(int(full["meta/frame_seed"]), 1)[0])
+    ctx.close()
+    assert np.array_equal(got.reshape(-1).view(np.uint32), full["f32/std/region_raw_f32"].reshape(-1).view(np.uint32))
+
+
 def test_cli_rejects_other_backends_and_missing_files(tmp_path):
     r = subprocess.run([CLI, "--backend", "hls"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unsupported backend" in r.stderr

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <filesystem>
+#include <fstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -53,7 +54,7 @@ void print_usage(const char *prog)
         "  --nms <float>         NMS IoU threshold (default: 0.45)\n"
         "  --hier <float>        Hierarchical threshold (accepted, unused by region layers)\n"
         "  --backend <hip>       Backend selector (hip = MI355X library; hls/cpu live in the reference build)\n"
-        "  --precision <int16>   Precision selector\n"
+        "  --precision <int16|fp32>  int16 = the batched fixed-point path; fp32 = the exact fp32 pass (one frame)\n"
         "  --batch <n>           Frames per accelerator call (default 1)\n"
         "  --device <n>          HIP device (default 0)\n"
         "  --json                Also print detections as JSON lines\n",
@@ -87,8 +88,10 @@ AppConfig parse_args(int argc, char **argv)
             }
         } else if (arg == "--precision" && need("")) {
             cfg.precision = argv[++i];
-            if (cfg.precision != "int16" && cfg.precision != "i16" && cfg.precision != "fixed") {
-                std::fprintf(stderr, "Unsupported precision: %s (the hip backend runs the int16 path)\n", cfg.precision.c_str());
+            if (cfg.precision == "float" || cfg.precision == "f32") cfg.precision = "fp32";
+            if (cfg.precision == "i16" || cfg.precision == "fixed") cfg.precision = "int16";
+            if (cfg.precision != "int16" && cfg.precision != "fp32") {
+                std::fprintf(stderr, "Unsupported precision: %s (the hip backend runs int16 and fp32)\n", cfg.precision.c_str());
                 std::exit(1);
             }
         } else if (arg.rfind("--", 0) == 0) {
@@ -142,8 +145,9 @@ void run_detector(AppConfig cfg)
         else fs::create_directories(prefix.parent_path());
         cfg.output_prefix = prefix.string();
     }
-    std::printf("YOLOv2 Object Detection - Starting\n  cfg:    %s\n  names:  %s\n  input:  %s\n  precision: int16\n  backend: hip (device %d, batch %d)\n  output: %s[.ppm]\n",
-                cfg.cfg_path.c_str(), cfg.names_path.c_str(), cfg.input_path.c_str(), cfg.device, cfg.batch, cfg.output_prefix.c_str());
+    std::printf("YOLOv2 Object Detection - Starting\n  cfg:    %s\n  names:  %s\n  input:  %s\n  precision: %s\n  backend: hip (device %d, batch %d)\n  output: %s[.ppm]\n",
+                cfg.cfg_path.c_str(), cfg.names_path.c_str(), cfg.input_path.c_str(), cfg.precision.c_str(), cfg.device, cfg.batch,
+                cfg.output_prefix.c_str());
 
     const y2h::Network net = y2h::parse_cfg(cfg.cfg_path);
     check_topology(net);
@@ -152,34 +156,56 @@ void run_detector(AppConfig cfg)
     std::printf("Input img: %s (w=%d, h=%d, c=%d)\n", cfg.input_path.c_str(), im.w, im.h, im.c);
     const y2h::Image sized = y2h::letterbox_image(im, net.w, net.h);
 
-    std::vector<int> wlen(yolo2_weight_len, yolo2_weight_len + YOLO2_N_CONV), blen(yolo2_bias_len, yolo2_bias_len + YOLO2_N_CONV);
-    const y2h::WeightsI16 wp = y2h::load_weights_int16(cfg.weights_dir, wlen, blen);
-
-    yolo2_hip_ctx *ctx = nullptr;
-    if (yolo2_hip_create(cfg.device, &ctx) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
-    if (yolo2_hip_load_weights_int16(ctx, wp.weights.data(), wp.weights.size(), wp.bias.data(), wp.bias.size(), wp.weight_q.data(),
-                                     (int)wp.weight_q.size(), wp.bias_q.data(), (int)wp.bias_q.size(), wp.act_q.data(),
-                                     (int)wp.act_q.size()) != YOLO2_SUCCESS)
-        throw std::runtime_error(yolo2_hip_last_error());
-    if (yolo2_hip_set_batch(ctx, cfg.batch) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
-
-    std::vector<float> frames((size_t)cfg.batch * YOLO2_FRAME_ELEMS);
-    for (int b = 0; b < cfg.batch; ++b) std::memcpy(frames.data() + (size_t)b * YOLO2_FRAME_ELEMS, sized.data.data(), sizeof(float) * YOLO2_FRAME_ELEMS);
-    std::vector<int16_t> region((size_t)cfg.batch * YOLO2_REGION_ELEMS);
-    int q = 0;
-    const auto t0 = std::chrono::high_resolution_clock::now();
-    if (yolo2_hip_run_batch_int16_host(ctx, frames.data(), cfg.batch, region.data(), &q) != YOLO2_SUCCESS)
-        throw std::runtime_error(yolo2_hip_last_error());
-    const double elapsed = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-    std::printf("%s: Predicted in %.3f seconds.\n", cfg.input_path.c_str(), elapsed);
-    std::printf("inference time: %.2f ms\n", elapsed * 1e3 / cfg.batch);  // line format parsed by scripts/yolo2_report.py:685-729
-    yolo2_hip_destroy(ctx);
-
-    // dequantise (yolo2_model.cpp:415-421), dumps with the reference's env-var names (:426-439, yolov2_main.cpp:297-306)
     const y2h::Layer &last = net.layers.back();
     std::vector<float> raw(YOLO2_REGION_ELEMS), proc(YOLO2_REGION_ELEMS);
-    const float scale = std::ldexp(1.0f, -q);
-    for (int t = 0; t < YOLO2_REGION_ELEMS; ++t) raw[t] = (float)region[t] * scale;
+    yolo2_hip_ctx *ctx = nullptr;
+    if (yolo2_hip_create(cfg.device, &ctx) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+    double elapsed = 0;
+    int frames_run = cfg.batch;
+    if (cfg.precision == "fp32") {
+        // weights/weights_reorg.bin + weights/bias.bin, the files load_weights() reads at Precision::FP32 (yolo2_model.cpp:171-183)
+        auto read_floats = [](const std::string &path, size_t want) {
+            std::ifstream f(path, std::ios::binary | std::ios::ate);
+            if (!f) throw std::runtime_error("Cannot open " + path);
+            const size_t n = (size_t)f.tellg() / sizeof(float);
+            if (n < want) throw std::runtime_error(path + " is too small (" + std::to_string(n) + " floats, need " + std::to_string(want) + ")");
+            std::vector<float> v(n);
+            f.seekg(0);
+            f.read(reinterpret_cast<char *>(v.data()), (std::streamsize)(n * sizeof(float)));
+            return v;
+        };
+        const std::vector<float> w = read_floats(cfg.weights_dir + "/weights_reorg.bin", (size_t)YOLO2_N_WEIGHTS);
+        const std::vector<float> b = read_floats(cfg.weights_dir + "/bias.bin", (size_t)YOLO2_N_BIAS);
+        if (yolo2_hip_load_weights_fp32(ctx, w.data(), w.size(), b.data(), b.size()) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        if (yolo2_hip_run_frame_fp32_host(ctx, sized.data.data(), raw.data()) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+        elapsed = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        frames_run = 1;
+    } else {
+        std::vector<int> wlen(yolo2_weight_len, yolo2_weight_len + YOLO2_N_CONV), blen(yolo2_bias_len, yolo2_bias_len + YOLO2_N_CONV);
+        const y2h::WeightsI16 wp = y2h::load_weights_int16(cfg.weights_dir, wlen, blen);
+        if (yolo2_hip_load_weights_int16(ctx, wp.weights.data(), wp.weights.size(), wp.bias.data(), wp.bias.size(), wp.weight_q.data(),
+                                         (int)wp.weight_q.size(), wp.bias_q.data(), (int)wp.bias_q.size(), wp.act_q.data(),
+                                         (int)wp.act_q.size()) != YOLO2_SUCCESS)
+            throw std::runtime_error(yolo2_hip_last_error());
+        if (yolo2_hip_set_batch(ctx, cfg.batch) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+        std::vector<float> frames((size_t)cfg.batch * YOLO2_FRAME_ELEMS);
+        for (int b = 0; b < cfg.batch; ++b) std::memcpy(frames.data() + (size_t)b * YOLO2_FRAME_ELEMS, sized.data.data(), sizeof(float) * YOLO2_FRAME_ELEMS);
+        std::vector<int16_t> region((size_t)cfg.batch * YOLO2_REGION_ELEMS);
+        int q = 0;
+        const auto t0 = std::chrono::high_resolution_clock::now();
+        if (yolo2_hip_run_batch_int16_host(ctx, frames.data(), cfg.batch, region.data(), &q) != YOLO2_SUCCESS)
+            throw std::runtime_error(yolo2_hip_last_error());
+        elapsed = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+        // dequantise (yolo2_model.cpp:415-421)
+        const float scale = std::ldexp(1.0f, -q);
+        for (int t = 0; t < YOLO2_REGION_ELEMS; ++t) raw[t] = (float)region[t] * scale;
+    }
+    std::printf("%s: Predicted in %.3f seconds.\n", cfg.input_path.c_str(), elapsed);
+    std::printf("inference time: %.2f ms\n", elapsed * 1e3 / frames_run);  // line format parsed by scripts/yolo2_report.py:685-729
+    yolo2_hip_destroy(ctx);
+
+    // dumps with the reference's env-var names (yolo2_model.cpp:426-439, yolov2_main.cpp:297-306)
     const char *nd = std::getenv("YOLO2_NO_DUMP");
     const bool do_dump = !(nd && nd[0] && nd[0] != '0');
     const char *raw_path = std::getenv("YOLO2_DUMP_REGION_RAW");
