@@ -343,6 +343,31 @@ def test_form_d_scaled_weights(qset, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fullnet_random_q_tables_vs_oracle(seed):
+    """Random per-layer Q tables (weight Q 12..15, bias Q 8..14, activation Q 7..11, incl. the route-28
+    alignment shift in both directions) and a different weight seed and gain: whatever mix of arithmetic
+    forms (A/B/C/D/64-bit) and kernels the loader and set_batch choose, batch 1 (split-K) and batch 3 must
+    equal the oracle bit for bit."""
+    rng = np.random.default_rng(seed)
+    wq = [int(v) for v in rng.integers(12, 16, 23)]
+    bq = [int(v) for v in rng.integers(8, 15, 23)]
+    aq = [14] + [int(v) for v in rng.integers(7, 12, 23)]
+    model = synth.SynthModel(seed=seed, weight_q=wq, bias_q=bq, act_q=aq, gain=float(rng.choice([0.7, 1.0, 1.6])))
+    frames = synth.frames(200 + seed, 3)
+    orclib.oracle().orc_set_threads(16)
+    want = [orclib.forward_i16(model, frames[f])[0] for f in range(3)]
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    counts = np.array(ctx.layer_path_counts()).sum(axis=0)
+    for batch in (1, 3):
+        region, q = ctx.run_batch_host(frames[:batch])
+        assert q == aq[23]
+        for f in range(batch):
+            assert np.array_equal(region[f].reshape(-1), want[f]), (batch, f, counts.tolist(), _diagnose(ctx, model, frames[f], f))
+    ctx.close()
+
+
 def test_extreme_weights_select_wide_path():
     """A weight set that can overflow int32 must be routed to the 64-bit kernel by the loader."""
     model = synth.SynthModel(seed=1)
