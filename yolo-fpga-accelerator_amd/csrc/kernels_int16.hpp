@@ -463,7 +463,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 // Legal when the host proved |t| < 2^29 and no int32 overflow (form A bound); CGin % 4 == 0.
 constexpr int kSplitBig = 1 << 29;
 
-template <int KS, int NST>
+// PACK (form D layers, shift = 16): the triples live in packed int16 pairs like form D's accumulators -
+// every increment pair is one v_perm_b32 of two dot results, l and h advance with one v_pk_add_i16 clamp
+// each and a with a WRAPPING packed add (16 cycles per step instead of ~30).  The true a is recovered at
+// the end: for x in [-32768, 32767], f(-32768) = l and f(32767) = h give  h - 32767 <= a <= l + 32768,
+// an interval shorter than 65536, so a mod 2^16 determines it (and when l == h, a no longer matters).
+template <int KS, int NST, bool PACK = false>
 __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                           const int2 *__restrict__ wpk,
                                                           const short *__restrict__ bias, const ConvArgs a)
@@ -496,6 +501,13 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     int ta[8], tl[8], th[8];   // the clamp-affine triple of this lane's sub-chain, per output channel
 #pragma unroll
     for (int m = 0; m < 8; ++m) { ta[m] = 0; tl[m] = -kSplitBig; th[m] = kSplitBig; }
+    short2_t pa[4], pl[4], ph[4];   // PACK: the same triples for channel pairs (2j, 2j+1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        pa[j] = short2_t{0, 0};
+        pl[j] = short2_t{(short)-32768, (short)-32768};
+        ph[j] = short2_t{(short)32767, (short)32767};
+    }
 
     const int r = a.round, s = a.shift;
     const int LtS = Lt * S, WS = WITEMS * S, total = LtS + WS;
@@ -542,14 +554,29 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
             int2 w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
+            if (PACK) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
-                d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
-                const int t = d >> s;
-                ta[m] += t;
-                tl[m] = clamp16(tl[m] + t);
-                th[m] = clamp16(th[m] + t);
+                for (int j = 0; j < 4; ++j) {
+                    int d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j].x), r, false);
+                    int d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j + 1].x), r, false);
+                    d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j].y), d0, false);
+                    d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j + 1].y), d1, false);
+                    // shift = 16: the increments are the high halves; gather both into one register
+                    const short2_t t = __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x07060302u));
+                    pa[j] = pa[j] + t;                                  // wraps mod 2^16 per half
+                    pl[j] = __builtin_elementwise_add_sat(pl[j], t);    // sat16(l + t)
+                    ph[j] = __builtin_elementwise_add_sat(ph[j], t);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
+                    d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
+                    const int t = d >> s;
+                    ta[m] += t;
+                    tl[m] = clamp16(tl[m] + t);
+                    th[m] = clamp16(th[m] + t);
+                }
             }
         }
         int2 *nxt = lds + (size_t)((it + 1) & 1) * buf_items;
@@ -558,6 +585,16 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
         __syncthreads();
     }
 
+    if (PACK) {   // unpack, recover the true sums (see the note above the kernel)
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int a16 = m & 1 ? pa[m >> 1].y : pa[m >> 1].x;
+            tl[m] = m & 1 ? pl[m >> 1].y : pl[m >> 1].x;
+            th[m] = m & 1 ? ph[m >> 1].y : ph[m >> 1].x;
+            const int lo = th[m] - 32767;
+            ta[m] = lo + ((a16 - lo) & 0xffff);
+        }
+    }
     // ordered combine across the four splits with wavefront shuffles: (s0,s1) and (s2,s3), then both halves
 #pragma unroll
     for (int delta = 16; delta <= 32; delta <<= 1) {

@@ -264,6 +264,13 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
 {
     if (p.splitk) {
         const int nst = (4 * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
+        const bool pack = p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK");   // form D layers: packed int16 triples
+        if (pack) {
+            if (p.K == 3) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_splitk<1, 2, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else hipLaunchKernelGGL((k_conv_i16_splitk<1, 8, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            return;
+        }
         if (p.K == 3) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
         else if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_splitk<1, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
         else hipLaunchKernelGGL((k_conv_i16_splitk<1, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
