@@ -468,16 +468,16 @@ constexpr int kSplitBig = 1 << 29;
 // each and a with a WRAPPING packed add (16 cycles per step instead of ~30).  The true a is recovered at
 // the end: for x in [-32768, 32767], f(-32768) = l and f(32767) = h give  h - 32767 <= a <= l + 32768,
 // an interval shorter than 65536, so a mod 2^16 determines it (and when l == h, a no longer matters).
-template <int KS, int NST, bool PACK = false>
+template <int KS, int NST, bool PACK = false, int S = 4>
 __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                           const int2 *__restrict__ wpk,
                                                           const short *__restrict__ bias, const ConvArgs a)
 {
     extern __shared__ int2 lds[];
-    constexpr int KK = KS * KS, WITEMS = KK * 32, S = 4, T = 16;
+    constexpr int KK = KS * KS, WITEMS = KK * 32, T = 64 / S;   // S K-splits x T pixels per wavefront
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int split = lane >> 4, pix = lane & 15;
+    const int split = lane / T, pix = lane % T;
     const int mb = a.mb_list ? a.mb_list[blockIdx.y] : (int)blockIdx.y;
     const int HW = a.H * a.W;
     const int q0 = blockIdx.x * T;
@@ -595,9 +595,9 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
             ta[m] = lo + ((a16 - lo) & 0xffff);
         }
     }
-    // ordered combine across the four splits with wavefront shuffles: (s0,s1) and (s2,s3), then both halves
+    // ordered combine across the splits with wavefront shuffles (tree: neighbours first)
 #pragma unroll
-    for (int delta = 16; delta <= 32; delta <<= 1) {
+    for (int delta = T; delta < 64; delta <<= 1) {
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const int a2 = __shfl_down(ta[m], delta), l2 = __shfl_down(tl[m], delta), h2 = __shfl_down(th[m], delta);

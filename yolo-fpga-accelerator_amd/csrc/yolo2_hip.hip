@@ -188,12 +188,14 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     }
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
-    if (p.splitk) {
-        const int lt = tile_items_bound(gin, 16, halo);
-        if (gin.CG % 4 != 0 || gin.CG < 16 || 4 * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
+    if (p.splitk) {   // splitk = number of K-splits S (4 or 8); 64/S pixels per wavefront
+        const int S = p.splitk, lt = tile_items_bound(gin, 64 / S, halo);
+        // (8 splits only for 1x1 layers: on the 3x3 layers the kernel is bound by re-staging the weight slices per
+        //  pixel tile, and halving the tile to 8 pixels measured 2x slower)
+        if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
     }
     if (p.splitk) p.P = 1;
-    const int T = p.splitk ? 16 : 64 * p.P;
+    const int T = p.splitk ? 64 / p.splitk : 64 * p.P;
     ConvArgs &a = p.args;
     // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
     a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
@@ -211,7 +213,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
-    p.lds_bytes = p.splitk ? 4 * (a.lt_max + p.K * p.K * 32) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
+    p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
     // XCD grid over (tiles, blocks): bytes crossing the fabric = input x Xm + weights x Xt x G, where
     // G > 1 only if the blocks one XCD owns do not keep their weights in its 4 MiB L2 (then every
@@ -263,17 +265,22 @@ static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const in
 static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
 {
     if (p.splitk) {
-        const int nst = (4 * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
+        const int nst = (p.splitk * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
         const bool pack = p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK");   // form D layers: packed int16 triples
+#define Y2_SPLITK(KSV, NSTV, PACKV, SV) \
+    hipLaunchKernelGGL((k_conv_i16_splitk<KSV, NSTV, PACKV, SV>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args)
+#define Y2_SPLITK_S(KSV, NSTV, PACKV) do { if (p.splitk == 8) Y2_SPLITK(KSV, NSTV, PACKV, 8); else Y2_SPLITK(KSV, NSTV, PACKV, 4); } while (0)
         if (pack) {
-            if (p.K == 3) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
-            else if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_splitk<1, 2, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
-            else hipLaunchKernelGGL((k_conv_i16_splitk<1, 8, true>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
-            return;
+            if (p.K == 3) Y2_SPLITK(3, 8, true, 4);
+            else if (nst <= 2) Y2_SPLITK_S(1, 2, true);
+            else Y2_SPLITK_S(1, 8, true);
+        } else {
+            if (p.K == 3) Y2_SPLITK(3, 8, false, 4);
+            else if (nst <= 2) Y2_SPLITK_S(1, 2, false);
+            else Y2_SPLITK_S(1, 8, false);
         }
-        if (p.K == 3) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
-        else if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_splitk<1, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
-        else hipLaunchKernelGGL((k_conv_i16_splitk<1, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+#undef Y2_SPLITK_S
+#undef Y2_SPLITK
         return;
     }
     if (p.K == 3) {
@@ -1106,24 +1113,24 @@ static int autotune(yolo2_hip_ctx *c)
             int bestSplit = 0;
             const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
-            for (int cfg = 0; cfg < 13; ++cfg) {
-                const int P = cfg == 12 ? 1 : 8 >> (cfg & 3);
-                const int pad = cfg == 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
+            for (int cfg = 0; cfg < 14; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits
+                const int P = cfg >= 12 ? 1 : 8 >> (cfg & 3);
+                const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
                 if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
                 ConvPlan cand = *sp;
                 cand.lds_pad = pad;
                 cand.splitk = 0;
-                if (cfg == 12) {
+                if (cfg >= 12) {
                     if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
-                    cand.splitk = 1;
+                    cand.splitk = cfg == 12 ? 4 : 8;
                 } else if (fs && atoi(fs) == 1 && sp->splitk_ok && c->extra[i].empty()) {
                     ConvPlan probe = *sp;
-                    probe.splitk = 1;
+                    probe.splitk = 4;
                     plan_conv(probe, tin.g, tout.g.cg_stride, out_base, CGout, 1);
                     if (probe.splitk) continue;   // forced: skip the ordinary candidates where split-K is available
                 }
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
-                if (cfg == 12 && !cand.splitk) continue;
+                if (cfg >= 12 && !cand.splitk) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
