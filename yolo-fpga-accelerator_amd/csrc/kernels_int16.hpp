@@ -475,12 +475,20 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
 {
     extern __shared__ int2 lds[];
     constexpr int KK = KS * KS, WITEMS = KK * 32, T = 64 / S;   // S K-splits x T pixels per wavefront
+    // LDS stride of a weight slice: +4 items, so that the S slices a wavefront reads from at once (same
+    // offset, one per split) start 32 bytes apart instead of on the same banks (2304 = 9 x 256 bytes)
+    constexpr int WSTR = WITEMS + 4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = lane / T, pix = lane % T;
-    const int mb = a.mb_list ? a.mb_list[blockIdx.y] : (int)blockIdx.y;
+    // same XCD grid as the tiled kernel: at one frame the input is tiny and the weights are everything, so
+    // the host picks Xm = 8 - all pixel tiles of a channel block run on ONE XCD and its weight slices cross
+    // the fabric once instead of once per XCD
+    int tile = blockIdx.x, yb = blockIdx.y;
+    if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
+    const int mb = a.mb_list ? a.mb_list[yb] : yb;
     const int HW = a.H * a.W;
-    const int q0 = blockIdx.x * T;
+    const int q0 = tile * T;
     const int qlast = min(q0 + T, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
     const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
@@ -492,11 +500,11 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     const int lo = fo - tile_start;
     const int Q = a.CGin / S;                               // channel groups per split
     // one LDS buffer = S input tiles (lt_max items each) followed by S weight slices (WITEMS each)
-    const int buf_items = S * (a.lt_max + WITEMS);
+    const int buf_items = S * (a.lt_max + WSTR);
     int rowaddr[KS];
 #pragma unroll
     for (int i = 0; i < KS; ++i) rowaddr[i] = (split * a.lt_max + ((KS == 3) ? (lo + (i - 1) * a.Wp - 1) : lo)) * 8;
-    const int waddr = (S * a.lt_max + split * WITEMS + wave * 8) * 8;   // this lane's weight slice, tap 0
+    const int waddr = (S * a.lt_max + split * WSTR + wave * 8) * 8;   // this lane's weight slice, tap 0
 
     int ta[8], tl[8], th[8];   // the clamp-affine triple of this lane's sub-chain, per output channel
 #pragma unroll
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
             const int jj = i - LtS, g = jj / WITEMS, j = jj - g * WITEMS;
             p0[k] = wsrc + (long)g * Q * WITEMS + j;
             pstep[k] = WITEMS;
-            slot[k] = S * a.lt_max + jj;
+            slot[k] = S * a.lt_max + g * WSTR + j;
         }
     }
     int2 stage[NST];
@@ -543,46 +551,67 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     __syncthreads();
 
     const char *lds_b = reinterpret_cast<const char *>(lds);
-    for (int it = 0; it < Q; ++it) {
-        const int itn = (it + 1 < Q) ? it + 1 : it;   // branch-free: the last iteration re-fetches itself
+    // Two iterations of global loads are in flight: at one frame a layer has only one or two workgroups per
+    // CU, so nothing else hides the latency of fetching the next tiles and weight slices; the loads of
+    // iteration it+2 are issued before the compute of it, those of it+1 (issued one iteration earlier) are
+    // committed to the other LDS buffer after it.  Two register sets alternate.
+    int2 stage_b[NST];
+    auto issue = [&](int2 (&dst)[NST], int itx) {
+        const int itc = min(itx, Q - 1);   // branch-free: past the end re-fetch the last iteration
 #pragma unroll
-        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) stage[k] = p0[k][(long)itn * pstep[k]]; }
+        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) dst[k] = p0[k][(long)itc * pstep[k]]; }
+    };
+    auto commit = [&](const int2 (&src)[NST], int bufidx) {
+        int2 *nxt = lds + (size_t)bufidx * buf_items;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) nxt[slot[k]] = src[k]; }
+    };
+    auto compute = [&](int it) {
         const char *buf = lds_b + (size_t)(it & 1) * buf_items * 8;
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
-            const int2 x = *reinterpret_cast<const int2 *>(buf + rowaddr[tap / KS] + (tap % KS) * 8);
-            int2 w[8];
+            for (int tap = 0; tap < KK; ++tap) {
+                const int2 x = *reinterpret_cast<const int2 *>(buf + rowaddr[tap / KS] + (tap % KS) * 8);
+                int2 w[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
-            if (PACK) {
+                for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
+                if (PACK) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j].x), r, false);
-                    int d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j + 1].x), r, false);
-                    d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j].y), d0, false);
-                    d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j + 1].y), d1, false);
-                    // shift = 16: the increments are the high halves; gather both into one register
-                    const short2_t t = __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x07060302u));
-                    pa[j] = pa[j] + t;                                  // wraps mod 2^16 per half
-                    pl[j] = __builtin_elementwise_add_sat(pl[j], t);    // sat16(l + t)
-                    ph[j] = __builtin_elementwise_add_sat(ph[j], t);
-                }
-            } else {
+                    for (int j = 0; j < 4; ++j) {
+                        int d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j].x), r, false);
+                        int d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j + 1].x), r, false);
+                        d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j].y), d0, false);
+                        d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j + 1].y), d1, false);
+                        // shift = 16: the increments are the high halves; gather both into one register
+                        const short2_t t = __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x07060302u));
+                        pa[j] = pa[j] + t;                                  // wraps mod 2^16 per half
+                        pl[j] = __builtin_elementwise_add_sat(pl[j], t);    // sat16(l + t)
+                        ph[j] = __builtin_elementwise_add_sat(ph[j], t);
+                    }
+                } else {
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
-                    d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
-                    const int t = d >> s;
-                    ta[m] += t;
-                    tl[m] = clamp16(tl[m] + t);
-                    th[m] = clamp16(th[m] + t);
+                    for (int m = 0; m < 8; ++m) {
+                        int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
+                        d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
+                        const int t = d >> s;
+                        ta[m] += t;
+                        tl[m] = clamp16(tl[m] + t);
+                        th[m] = clamp16(th[m] + t);
+                    }
                 }
             }
-        }
-        int2 *nxt = lds + (size_t)((it + 1) & 1) * buf_items;
-#pragma unroll
-        for (int k = 0; k < NST; ++k) { const int i = tid + k * 256; if (i < total) nxt[slot[k]] = stage[k]; }
+    };
+    issue(stage, 1);
+    for (int it = 0; it < Q; it += 2) {
+        issue(stage_b, it + 2);
+        compute(it);
+        commit(stage, (it + 1) & 1);
         __syncthreads();
+        if (it + 1 < Q) {
+            issue(stage, it + 3);
+            compute(it + 1);
+            commit(stage_b, it & 1);
+            __syncthreads();
+        }
     }
 
     if (PACK) {   // unpack, recover the true sums (see the note above the kernel)
