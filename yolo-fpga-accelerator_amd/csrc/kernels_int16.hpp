@@ -468,13 +468,16 @@ constexpr int kSplitBig = 1 << 29;
 // each and a with a WRAPPING packed add (16 cycles per step instead of ~30).  The true a is recovered at
 // the end: for x in [-32768, 32767], f(-32768) = l and f(32767) = h give  h - 32767 <= a <= l + 32768,
 // an interval shorter than 65536, so a mod 2^16 determines it (and when l == h, a no longer matters).
-template <int KS, int NST, bool PACK = false, int S = 4>
+// PP (1 or 2): pixels per lane.  The per-iteration cost (stage, barrier, LDS round trip) dominates at one
+// frame, so two pixel tiles per wavefront share one staged set of weight slices and input tiles.
+template <int KS, int NST, bool PACK = false, int S = 4, int PP = 1>
 __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                           const int2 *__restrict__ wpk,
                                                           const short *__restrict__ bias, const ConvArgs a)
 {
     extern __shared__ int2 lds[];
-    constexpr int KK = KS * KS, WITEMS = KK * 32, T = 64 / S;   // S K-splits x T pixels per wavefront
+    constexpr int KK = KS * KS, WITEMS = KK * 32, T = 64 / S;   // S K-splits x T pixels per wavefront (x PP per lane)
+    constexpr int TT = T * PP;                                  // pixels per workgroup tile
     // LDS stride of a weight slice: +4 items, so that the S slices a wavefront reads from at once (same
     // offset, one per split) start 32 bytes apart instead of on the same banks (2304 = 9 x 256 bytes)
     constexpr int WSTR = WITEMS + 4;
@@ -488,33 +491,40 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
     const int mb = a.mb_list ? a.mb_list[yb] : yb;
     const int HW = a.H * a.W;
-    const int q0 = tile * T;
-    const int qlast = min(q0 + T, a.npix) - 1;
+    const int q0 = tile * TT;
+    const int qlast = min(q0 + TT, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
     const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
     const int tile_start = fmin - halo;
     const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
-    const int q = min(q0 + pix, qlast);
-    const bool valid = (q0 + pix <= qlast) && split == 0;   // split-0 lanes hold the combined result
-    const int fo = flat_of(q, HW, a.W, a.Wp, a.PL);
-    const int lo = fo - tile_start;
     const int Q = a.CGin / S;                               // channel groups per split
-    // one LDS buffer = S input tiles (lt_max items each) followed by S weight slices (WITEMS each)
+    // one LDS buffer = S input tiles (lt_max items each) followed by S weight slices (WSTR each)
     const int buf_items = S * (a.lt_max + WSTR);
-    int rowaddr[KS];
+    bool valid[PP];
+    int fo[PP], rowaddr[PP][KS];
 #pragma unroll
-    for (int i = 0; i < KS; ++i) rowaddr[i] = (split * a.lt_max + ((KS == 3) ? (lo + (i - 1) * a.Wp - 1) : lo)) * 8;
+    for (int p = 0; p < PP; ++p) {
+        const int qp = q0 + pix + p * T;
+        valid[p] = (qp <= qlast) && split == 0;             // split-0 lanes hold the combined result
+        fo[p] = flat_of(min(qp, qlast), HW, a.W, a.Wp, a.PL);
+        const int lo = fo[p] - tile_start;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) rowaddr[p][i] = (split * a.lt_max + ((KS == 3) ? (lo + (i - 1) * a.Wp - 1) : lo)) * 8;
+    }
     const int waddr = (S * a.lt_max + split * WSTR + wave * 8) * 8;   // this lane's weight slice, tap 0
 
-    int ta[8], tl[8], th[8];   // the clamp-affine triple of this lane's sub-chain, per output channel
+    int ta[PP][8], tl[PP][8], th[PP][8];   // the clamp-affine triple of this lane's sub-chain, per pixel and output channel
+    short2_t pa[PP][4], pl[PP][4], ph[PP][4];   // PACK: the same triples for channel pairs (2j, 2j+1)
 #pragma unroll
-    for (int m = 0; m < 8; ++m) { ta[m] = 0; tl[m] = -kSplitBig; th[m] = kSplitBig; }
-    short2_t pa[4], pl[4], ph[4];   // PACK: the same triples for channel pairs (2j, 2j+1)
+    for (int p = 0; p < PP; ++p) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        pa[j] = short2_t{0, 0};
-        pl[j] = short2_t{(short)-32768, (short)-32768};
-        ph[j] = short2_t{(short)32767, (short)32767};
+        for (int m = 0; m < 8; ++m) { ta[p][m] = 0; tl[p][m] = -kSplitBig; th[p][m] = kSplitBig; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            pa[p][j] = short2_t{0, 0};
+            pl[p][j] = short2_t{(short)-32768, (short)-32768};
+            ph[p][j] = short2_t{(short)32767, (short)32767};
+        }
     }
 
     const int r = a.round, s = a.shift;
@@ -569,36 +579,41 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     auto compute = [&](int it) {
         const char *buf = lds_b + (size_t)(it & 1) * buf_items * 8;
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap) {
-                const int2 x = *reinterpret_cast<const int2 *>(buf + rowaddr[tap / KS] + (tap % KS) * 8);
-                int2 w[8];
+        for (int tap = 0; tap < KK; ++tap) {
+            int2 x[PP];
 #pragma unroll
-                for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
+            for (int p = 0; p < PP; ++p) x[p] = *reinterpret_cast<const int2 *>(buf + rowaddr[p][tap / KS] + (tap % KS) * 8);
+            int2 w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const int2 *>(buf + waddr + (tap * 32 + m) * 8);
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
                 if (PACK) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        int d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j].x), r, false);
-                        int d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[2 * j + 1].x), r, false);
-                        d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j].y), d0, false);
-                        d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[2 * j + 1].y), d1, false);
+                        int d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].x), __builtin_bit_cast(short2_t, w[2 * j].x), r, false);
+                        int d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].x), __builtin_bit_cast(short2_t, w[2 * j + 1].x), r, false);
+                        d0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].y), __builtin_bit_cast(short2_t, w[2 * j].y), d0, false);
+                        d1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].y), __builtin_bit_cast(short2_t, w[2 * j + 1].y), d1, false);
                         // shift = 16: the increments are the high halves; gather both into one register
                         const short2_t t = __builtin_bit_cast(short2_t, __builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, 0x07060302u));
-                        pa[j] = pa[j] + t;                                  // wraps mod 2^16 per half
-                        pl[j] = __builtin_elementwise_add_sat(pl[j], t);    // sat16(l + t)
-                        ph[j] = __builtin_elementwise_add_sat(ph[j], t);
+                        pa[p][j] = pa[p][j] + t;                                  // wraps mod 2^16 per half
+                        pl[p][j] = __builtin_elementwise_add_sat(pl[p][j], t);    // sat16(l + t)
+                        ph[p][j] = __builtin_elementwise_add_sat(ph[p][j], t);
                     }
                 } else {
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
-                        int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), __builtin_bit_cast(short2_t, w[m].x), r, false);
-                        d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), __builtin_bit_cast(short2_t, w[m].y), d, false);
+                        int d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].x), __builtin_bit_cast(short2_t, w[m].x), r, false);
+                        d = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x[p].y), __builtin_bit_cast(short2_t, w[m].y), d, false);
                         const int t = d >> s;
-                        ta[m] += t;
-                        tl[m] = clamp16(tl[m] + t);
-                        th[m] = clamp16(th[m] + t);
+                        ta[p][m] += t;
+                        tl[p][m] = clamp16(tl[p][m] + t);
+                        th[p][m] = clamp16(th[p][m] + t);
                     }
                 }
             }
+        }
     };
     issue(stage, 1);
     for (int it = 0; it < Q; it += 2) {
@@ -614,46 +629,49 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
         }
     }
 
-    if (PACK) {   // unpack, recover the true sums (see the note above the kernel)
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int a16 = m & 1 ? pa[m >> 1].y : pa[m >> 1].x;
-            tl[m] = m & 1 ? pl[m >> 1].y : pl[m >> 1].x;
-            th[m] = m & 1 ? ph[m >> 1].y : ph[m >> 1].x;
-            const int lo = th[m] - 32767;
-            ta[m] = lo + ((a16 - lo) & 0xffff);
-        }
-    }
-    // ordered combine across the splits with wavefront shuffles (tree: neighbours first)
-#pragma unroll
-    for (int delta = T; delta < 64; delta <<= 1) {
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const int a2 = __shfl_down(ta[m], delta), l2 = __shfl_down(tl[m], delta), h2 = __shfl_down(th[m], delta);
-            // this lane's map runs first, the partner's (higher split) second: f = f2 o f1
-            tl[m] = min(max(tl[m] + a2, l2), h2);
-            th[m] = min(max(th[m] + a2, l2), h2);
-            ta[m] += a2;
-        }
-    }
-    // apply to the shifted (unsaturated) bias, integer leaky, store 2 items (8 channels) per pixel
     const short *bp = bias + mb * 32 + wave * 8;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        const int cgo = mb * 8 + wave * 2 + g;
-        int v[4];
+    for (int p = 0; p < PP; ++p) {
+        if (PACK) {   // unpack, recover the true sums (see the note above the kernel)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int m = g * 4 + t;
-            const int b = bp[m];
-            const int b0 = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
-            int e = min(max(b0 + ta[m], tl[m]), th[m]);
-            v[t] = a.leaky ? leaky_i16(e) : e;
+            for (int m = 0; m < 8; ++m) {
+                const int a16 = m & 1 ? pa[p][m >> 1].y : pa[p][m >> 1].x;
+                tl[p][m] = m & 1 ? pl[p][m >> 1].y : pl[p][m >> 1].x;
+                th[p][m] = m & 1 ? ph[p][m >> 1].y : ph[p][m >> 1].x;
+                const int lo = th[p][m] - 32767;
+                ta[p][m] = lo + ((a16 - lo) & 0xffff);
+            }
         }
-        int2 o;
-        o.x = (v[0] & 0xffff) | (v[1] << 16);
-        o.y = (v[2] & 0xffff) | (v[3] << 16);
-        if (valid && cgo < a.CGout) out[a.out_base + (long)cgo * a.out_cg_stride + fo] = o;
+        // ordered combine across the splits with wavefront shuffles (tree: neighbours first)
+#pragma unroll
+        for (int delta = T; delta < 64; delta <<= 1) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int a2 = __shfl_down(ta[p][m], delta), l2 = __shfl_down(tl[p][m], delta), h2 = __shfl_down(th[p][m], delta);
+                // this lane's map runs first, the partner's (higher split) second: f = f2 o f1
+                tl[p][m] = min(max(tl[p][m] + a2, l2), h2);
+                th[p][m] = min(max(th[p][m] + a2, l2), h2);
+                ta[p][m] += a2;
+            }
+        }
+        // apply to the shifted (unsaturated) bias, integer leaky, store 2 items (8 channels) per pixel
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int cgo = mb * 8 + wave * 2 + g;
+            int v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = g * 4 + t;
+                const int b = bp[m];
+                const int b0 = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
+                int e = min(max(b0 + ta[p][m], tl[p][m]), th[p][m]);
+                v[t] = a.leaky ? leaky_i16(e) : e;
+            }
+            int2 o;
+            o.x = (v[0] & 0xffff) | (v[1] << 16);
+            o.y = (v[2] & 0xffff) | (v[3] << 16);
+            if (valid[p] && cgo < a.CGout) out[a.out_base + (long)cgo * a.out_cg_stride + fo[p]] = o;
+        }
     }
 }
 

@@ -164,7 +164,8 @@ struct ConvPlan {
     int P = 8;
     int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
-    int splitk = 0;            // small batches: 16 pixels x 4 K-splits per wavefront, shuffle-combined (k_conv_i16_splitk)
+    int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
+    int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
     int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
     int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
                                // fewer co-resident workgroups finish sooner each, which shortens the
@@ -189,13 +190,14 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
     if (p.splitk) {   // splitk = number of K-splits S (4 or 8); 64/S pixels per wavefront
-        const int S = p.splitk, lt = tile_items_bound(gin, 64 / S, halo);
+        if (p.splitk_pp == 2 && !(p.splitk == 4 && p.K == 3 && p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK"))) p.splitk_pp = 1;   // only built for 3x3 form D layers
+        const int S = p.splitk, lt = tile_items_bound(gin, 64 / S * p.splitk_pp, halo);
         // (8 splits only for 1x1 layers: on the 3x3 layers the kernel is bound by re-staging the weight slices per
         //  pixel tile, and halving the tile to 8 pixels measured 2x slower)
         if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
     }
     if (p.splitk) p.P = 1;
-    const int T = p.splitk ? 64 / p.splitk : 64 * p.P;
+    const int T = p.splitk ? 64 / p.splitk * p.splitk_pp : 64 * p.P;
     ConvArgs &a = p.args;
     // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
     a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
@@ -271,7 +273,8 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
     hipLaunchKernelGGL((k_conv_i16_splitk<KSV, NSTV, PACKV, SV>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args)
 #define Y2_SPLITK_S(KSV, NSTV, PACKV) do { if (p.splitk == 8) Y2_SPLITK(KSV, NSTV, PACKV, 8); else Y2_SPLITK(KSV, NSTV, PACKV, 4); } while (0)
         if (pack) {
-            if (p.K == 3) Y2_SPLITK(3, 8, true, 4);
+            if (p.K == 3 && p.splitk_pp == 2) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else if (p.K == 3) Y2_SPLITK(3, 8, true, 4);
             else if (nst <= 2) Y2_SPLITK_S(1, 2, true);
             else Y2_SPLITK_S(1, 8, true);
         } else {
@@ -1110,19 +1113,21 @@ static int autotune(yolo2_hip_ctx *c)
         for (ConvPlan *sp : subs) {
             float best = 1e30f;
             int bestP = sp->P, bestPad = 0;
-            int bestSplit = 0;
+            int bestSplit = 0, bestPP = 1;
             const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
-            for (int cfg = 0; cfg < 14; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits
+            for (int cfg = 0; cfg < 15; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14: 4 splits, 2 pixels per lane
                 const int P = cfg >= 12 ? 1 : 8 >> (cfg & 3);
                 const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
                 if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
                 ConvPlan cand = *sp;
                 cand.lds_pad = pad;
                 cand.splitk = 0;
+                cand.splitk_pp = 1;
                 if (cfg >= 12) {
                     if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
-                    cand.splitk = cfg == 12 ? 4 : 8;
+                    cand.splitk = cfg == 13 ? 8 : 4;
+                    cand.splitk_pp = cfg == 14 ? 2 : 1;
                 } else if (fs && atoi(fs) == 1 && sp->splitk_ok && c->extra[i].empty()) {
                     ConvPlan probe = *sp;
                     probe.splitk = 4;
@@ -1131,6 +1136,7 @@ static int autotune(yolo2_hip_ctx *c)
                 }
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
                 if (cfg >= 12 && !cand.splitk) continue;
+                if (cfg == 14 && cand.splitk_pp != 2) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
@@ -1146,10 +1152,11 @@ static int autotune(yolo2_hip_ctx *c)
                 if (getenv("YOLO2_VERBOSE"))
                     fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
                             cand.splitk, cand.grid.x, cand.grid.y, tmin * 1e3);
-                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; }
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; }
             }
             sp->lds_pad = bestPad;
             sp->splitk = bestSplit;
+            sp->splitk_pp = bestPP;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
         ord++;
