@@ -190,7 +190,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     const int halo = p.K == 3 ? gin.Wp + 1 : 0;
     while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
     if (p.splitk) {   // splitk = number of K-splits S (4 or 8); 64/S pixels per wavefront
-        if (p.splitk_pp == 2 && !(p.splitk == 4 && p.K == 3 && p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK"))) p.splitk_pp = 1;   // only built for 3x3 form D layers
+        if (p.splitk_pp > 1 && !(p.splitk == 4 && p.K == 3 && p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK"))) p.splitk_pp = 1;   // only built for 3x3 form D layers
         const int S = p.splitk, lt = tile_items_bound(gin, 64 / S * p.splitk_pp, halo);
         // (8 splits only for 1x1 layers: on the 3x3 layers the kernel is bound by re-staging the weight slices per
         //  pixel tile, and halving the tile to 8 pixels measured 2x slower)
@@ -273,7 +273,8 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
     hipLaunchKernelGGL((k_conv_i16_splitk<KSV, NSTV, PACKV, SV>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args)
 #define Y2_SPLITK_S(KSV, NSTV, PACKV) do { if (p.splitk == 8) Y2_SPLITK(KSV, NSTV, PACKV, 8); else Y2_SPLITK(KSV, NSTV, PACKV, 4); } while (0)
         if (pack) {
-            if (p.K == 3 && p.splitk_pp == 2) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            if (p.K == 3 && p.splitk_pp == 4) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 4>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else if (p.K == 3 && p.splitk_pp == 2) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
             else if (p.K == 3) Y2_SPLITK(3, 8, true, 4);
             else if (nst <= 2) Y2_SPLITK_S(1, 2, true);
             else Y2_SPLITK_S(1, 8, true);
@@ -1116,7 +1117,7 @@ static int autotune(yolo2_hip_ctx *c)
             int bestSplit = 0, bestPP = 1;
             const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
-            for (int cfg = 0; cfg < 15; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14: 4 splits, 2 pixels per lane
+            for (int cfg = 0; cfg < 16; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14: 4 splits, 2 pixels per lane
                 const int P = cfg >= 12 ? 1 : 8 >> (cfg & 3);
                 const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
                 if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
@@ -1127,7 +1128,7 @@ static int autotune(yolo2_hip_ctx *c)
                 if (cfg >= 12) {
                     if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
                     cand.splitk = cfg == 13 ? 8 : 4;
-                    cand.splitk_pp = cfg == 14 ? 2 : 1;
+                    cand.splitk_pp = cfg == 14 ? 2 : (cfg == 15 ? 4 : 1);
                 } else if (fs && atoi(fs) == 1 && sp->splitk_ok && c->extra[i].empty()) {
                     ConvPlan probe = *sp;
                     probe.splitk = 4;
@@ -1137,6 +1138,7 @@ static int autotune(yolo2_hip_ctx *c)
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
                 if (cfg >= 12 && !cand.splitk) continue;
                 if (cfg == 14 && cand.splitk_pp != 2) continue;
+                if (cfg == 15 && cand.splitk_pp != 4) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 2; ++rep) {
