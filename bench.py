@@ -316,6 +316,8 @@ def main():
                             "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
                             "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
         traffic, traffic_src = hbm_traffic_per_launch(key[0], B)
+        fam = [l for l in net.CONVS if l.size == key[0]]     # the scope of `traffic`: all launches of this kernel size
+        fam_alg = sum(conv_layer_bytes(l, Bl) for l in fam) / len(fam)
         result = {
             "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -328,6 +330,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                         "traffic_scope": f"mean over the {len(fam)} conv{key[0]}x{key[0]} launches per lane and step (autotune may change the "
+                                          "pixels-per-lane instantiation between runs); L2-to-fabric bytes, Infinity Cache hits included",
+                         "algorithmic_bytes_per_launch_same_scope": fam_alg,
                          "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]},
             "valu_roofline": valu,
             "layer_ms": [round(float(x), 4) for x in layer_ms],
