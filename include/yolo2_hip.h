@@ -202,7 +202,7 @@ int yolo2_hip_layer_times_ms(yolo2_hip_ctx *ctx, float *ms32 /* [32] */);
 int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 
 /* Launch geometry of the conv kernel family, for the roofline report.  pixels_per_lane = 0 means
- * the layer runs the split-K kernel (16 pixels x 4 K-splits per wavefront, partial clamp-affine
+ * the layer runs the split-K kernel (64/S pixels x S K-splits per wavefront, partial clamp-affine
  * maps combined with wavefront shuffles), which set_batch picks for small batches when it times
  * faster; YOLO2_SPLITK=0 / 1 in the environment disables / forces it wherever its bounds hold. */
 int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x, int *grid_y,

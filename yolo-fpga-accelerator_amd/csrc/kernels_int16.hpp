@@ -454,13 +454,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 // split bit-exactly: each step is the map x -> clamp(x + t, -32768, 32767), and such clamp-affine
 // maps  f(x) = clamp(x + a, l, h)  are closed under composition:
 //     (f2 o f1)(x) = clamp(x + a1 + a2, clamp(l1 + a2, l2, h2), clamp(h1 + a2, l2, h2)).
-// A wavefront here is 16 pixels x 4 K-splits (lane = split*16 + pixel): split s runs channel groups
-// [s*CGin/4, (s+1)*CGin/4) and carries the triple (a, l, h) of its sub-chain per output channel
-// instead of a value; at the end the four triples are combined IN ORDER with two rounds of
-// wavefront shuffles (__shfl_down 16, then 32) and applied to the shifted bias.  Because the splits
-// use different channel groups, the weights are lane-dependent: the four 32-channel weight slices
-// are staged through LDS next to the four input tiles and read into VGPRs.
-// Legal when the host proved |t| < 2^29 and no int32 overflow (form A bound); CGin % 4 == 0.
+// A wavefront here is T = 64/S pixels x S K-splits (S = 4, or 8 on 1x1 layers; lane = split*T + pixel,
+// optionally PP = 2 or 4 pixels per lane): split s runs channel groups [s*CGin/S, (s+1)*CGin/S) and
+// carries the triple (a, l, h) of its sub-chain per output channel instead of a value; at the end the S
+// triples are combined IN ORDER with log2(S) rounds of wavefront shuffles (__shfl_down T, 2T, ..) and
+// applied to the shifted bias.  Because the splits use different channel groups, the weights are
+// lane-dependent: the S 32-channel weight slices are staged through LDS next to the S input tiles and
+// read into VGPRs.
+// Legal when the host proved |t| < 2^29 and no int32 overflow (form A bound); CGin % S == 0.
 constexpr int kSplitBig = 1 << 29;
 
 // PACK (form D layers, shift = 16): the triples live in packed int16 pairs like form D's accumulators -
