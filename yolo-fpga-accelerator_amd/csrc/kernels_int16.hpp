@@ -255,8 +255,10 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     constexpr bool X64 = MODE == 2;
     typedef typename std::conditional<X64, long, int>::type acc_t;
     constexpr int T = 64 * P;
-    constexpr int KK = KS * KS * GRP;   // "taps" per barrier: spatial taps, or channel groups for GRP > 1
-    static_assert(GRP == 1 || KS == 1, "grouping is for 1x1 convs");
+    constexpr int KT = KS * KS;         // spatial taps per channel group
+    constexpr int KK = KT * GRP;        // "taps" per barrier (taps of GRP consecutive channel groups)
+    constexpr int PFG = KS == 1 ? GRP : 1;   // channel groups whose input values are fetched from LDS in one batch
+    static_assert(GRP == 1 || KS == 1 || (KS == 3 && GRP == 2), "grouping: 1x1 convs (8 groups per barrier); 3x3 with 2 groups works but measured slower, not launched");
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     if (MODE != 2) asm volatile("" : "+v"(r_vgpr));
     const char *lds_b = reinterpret_cast<const char *>(lds);
     const int2 *src = in + kLead + tile_start;
-    const int2 *wq = wpk + ((long)mb * a.CGin * (KS * KS) * 32 + wave * 8);   // [mb][cg][tap][32]: KS*KS taps per group
+    const int2 *wq = wpk + ((long)mb * a.CGin * KT * 32 + wave * 8);   // [mb][cg][tap][32]: KT taps per group
 
     // Input tiles are double-buffered in LDS: the global loads of group cg+1 are issued before the
     // compute on group cg and written to the other buffer after it, so HBM/L2 latency hides behind
@@ -361,26 +363,30 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
         // Small tiles (P <= 2): fetch the whole group's input values up front, so the LDS latency of a
         // tap is not exposed when few wavefronts are resident (the tail of a launch at modest batch).
         constexpr bool PREX = (MODE == 3 || MODE == 4) && P <= PREX_MAX_P;
-        int2 xv[PREX ? KK : 1][P];
+        // LDS address of "tap" t of pixel p: group t / KT of this barrier interval, spatial tap t % KT
+        auto xaddr = [&](int t, int p) -> const int2 * {
+            return reinterpret_cast<const int2 *>(tile + (t / KT) * (a.lt_max * 8) + rowaddr[p][(t % KT) / KS] + ((t % KT) % KS) * 8);
+        };
+#pragma unroll
+        for (int gb = 0; gb < GRP / PFG; ++gb) {
+        int2 xv[PREX ? KT * PFG : 1][P];
         if (PREX) {
 #pragma unroll
-            for (int tap = 0; tap < KK; ++tap)
+            for (int tt = 0; tt < KT * PFG; ++tt)
 #pragma unroll
-                for (int p = 0; p < P; ++p)
-                    xv[tap][p] = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
-                                            : *reinterpret_cast<const int2 *>(tile + tap * a.lt_max * 8 + rowaddr[p][0]);
+                for (int p = 0; p < P; ++p) xv[tt][p] = *xaddr(gb * KT * PFG + tt, p);
         }
 #pragma unroll
-        for (int tap = 0; tap < KK; ++tap) {
+        for (int tt = 0; tt < KT * PFG; ++tt) {
+            const int tap = gb * KT * PFG + tt;
             int2 w[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 int2 x;
-                if (PREX) x = xv[tap][p];
-                else x = (GRP == 1) ? *reinterpret_cast<const int2 *>(tile + rowaddr[p][tap / KS] + (tap % KS) * 8)
-                                    : *reinterpret_cast<const int2 *>(tile + tap * a.lt_max * 8 + rowaddr[p][0]);
+                if (PREX) x = xv[tt][p];
+                else x = *xaddr(tap, p);
                 // Form A's dot products do not depend on the accumulators, so hipcc would compute
                 // all 72x8 of a group up front (hundreds of live registers, SGPR spills).  An empty
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
@@ -407,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             // form A: without a fence between taps hipcc hoists the scalar weight loads of all
             // nine taps (144 SGPRs) to the top of the group and spills them
             if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
+        }
         }
         {
             int2 *nxt = lds + ((cg + 1) & 1) * buf_items;

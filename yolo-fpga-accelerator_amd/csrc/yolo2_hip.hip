@@ -215,6 +215,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
+    // (two channel groups per barrier for the 3x3 forms C/D - one barrier per 18 taps - was measured: -1 to -2 %)
     p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32 + 4) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
     // XCD grid over (tiles, blocks): bytes crossing the fabric = input x Xm + weights x Xt x G, where
