@@ -284,8 +284,8 @@ def main():
     if rank == 0:
         fps = world * B * args.steps / dt
         paths = ctx.layer_paths()
-        lanes = ctx.num_lanes()          # 2: every layer is two concurrent half-batch launches
-        Bl = B // lanes                  # frames per launch
+        lanes = ctx.num_lanes()          # every layer is `lanes` concurrent part-batch launches (3 at batch 64: 22 + 21 + 21)
+        Bl = (B + lanes - 1) // lanes    # frames per launch of lane 0, the one the per-layer hipEvents time
         # dominant kernel = the conv kernel instantiation with the largest total time
         groups = {}
         for l in net.CONVS:

@@ -195,10 +195,10 @@ int yolo2_hip_debug_layer_output(yolo2_hip_ctx *ctx, int layer_idx, int frame, i
 int yolo2_hip_set_profiling(yolo2_hip_ctx *ctx, int enable);
 int yolo2_hip_layer_times_ms(yolo2_hip_ctx *ctx, float *ms32 /* [32] */);
 
-/* A batch >= 16 runs as two half-batches ("lanes") on two internal streams forked from and joined
- * to the caller's stream, so that every layer is two concurrent launches and one's idle tail is
- * filled by the other (+4-5 % frames/s at batch 64).  Returns 1 or 2.  Per-layer times and launch
- * geometry then describe lane 0's half-batch launches. */
+/* A batch >= 16 runs as two, a batch of 48..127 as three part-batches ("lanes", sizes within one frame of
+ * each other) on internal streams forked from and joined to the caller's stream, so that every layer is
+ * several concurrent launches and one's idle tail is filled by the others (+4-6 % frames/s at batch 64).
+ * Returns the lane count (1 = none).  Per-layer times and launch geometry then describe lane 0's launches. */
 int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 
 /* Launch geometry of the conv kernel family, for the roofline report.  pixels_per_lane = 0 means

@@ -24,6 +24,6 @@ for r in tail:
 tot = sum(sum(v) for v in agg.values())
 span = int(tail[-1]["End_Timestamp"]) - int(tail[0]["Start_Timestamp"])
 print(f"# timed steps only: {steps} steps x {D} dispatches; sum of kernel durations {tot/1e6/steps:.3f} ms/step, "
-      f"first start to last end {span/1e6/steps:.3f} ms/step (launches of the two lanes overlap)")
+      f"first start to last end {span/1e6/steps:.3f} ms/step (launches of the lanes overlap)")
 for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
     print(f"{name[:70]:70s} launches/step={len(v)//steps:3d} avg_us={sum(v)/len(v)/1e3:9.2f} min_us={min(v)/1e3:9.2f} max_us={max(v)/1e3:9.2f} pct={100*sum(v)/tot:6.2f}")

@@ -674,6 +674,7 @@ struct yolo2_hip_ctx {
     // one (a layer is only a few workgroup-generations long at batch 64) is filled by the other:
     // +4 % frames/s at batch 64.  A lane is a child context that shares the parent's weights.
     std::vector<yolo2_hip_ctx *> lanes;
+    std::vector<int> lane_first;       // first frame of each lane within the batch
     bool is_lane = false, laned = false;
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -744,6 +745,7 @@ static void free_f16_activations(yolo2_hip_ctx *c)
 
 static void destroy_lanes(yolo2_hip_ctx *c)
 {
+    c->lane_first.clear();
     for (yolo2_hip_ctx *l : c->lanes) yolo2_hip_destroy(l);
     c->lanes.clear();
     c->laned = false;
@@ -1208,25 +1210,33 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
     if (!c->weights_loaded) return fail(YOLO2_ERROR, "load weights before set_batch");
     HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
-    int nl = 2;   // YOLO2_LANES=n: experiment hook (default two lanes)
+    // Lanes: three for batches 48..127 (measured +2 % over two at batch 64: one more launch to fill each tail; at
+    // batch 256 two are 1 % better), two otherwise from batch 16; YOLO2_LANES=n overrides.  Sizes differ by at
+    // most one frame (64 = 22 + 21 + 21).
+    int nl = (batch >= 48 && batch < 128) ? 3 : 2;
     if (const char *e = getenv("YOLO2_LANES")) nl = std::max(1, atoi(e));
-    const bool want_lanes = !c->is_lane && nl > 1 && batch >= 8 * nl && batch % nl == 0 && !getenv("YOLO2_NO_LANES");
+    const bool want_lanes = !c->is_lane && nl > 1 && batch >= 8 * nl && !getenv("YOLO2_NO_LANES");
     if (!want_lanes) {
         destroy_lanes(c);
         return set_batch_single(c, batch);
     }
-    if (c->laned && c->batch == batch) return YOLO2_SUCCESS;
+    if (c->laned && c->batch == batch && (int)c->lanes.size() == nl) return YOLO2_SUCCESS;
     destroy_lanes(c);
     free_activations(c);
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
+    c->lane_first.clear();
+    int first = 0;
     for (int i = 0; i < nl; ++i) {
         yolo2_hip_ctx *l = nullptr;
+        const int frames = batch / nl + (i < batch % nl ? 1 : 0);
         int rc = make_lane(c, &l);
         if (rc == YOLO2_SUCCESS) {
             c->lanes.push_back(l);
-            rc = set_batch_single(l, batch / nl);
+            c->lane_first.push_back(first);
+            rc = set_batch_single(l, frames);
         }
         if (rc) { destroy_lanes(c); return rc; }
+        first += frames;
     }
     if (c->prof) (void)yolo2_hip_set_profiling(c->lanes[0], 1);
     c->batch = batch;
@@ -1350,13 +1360,14 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
     }
     hipStream_t st = (hipStream_t)stream;
     if (c->laned) {   // fork the two half-batches onto the lane streams, join back into the caller's stream
-        const int nl = (int)c->lanes.size(), half = batch / nl;
+        const int nl = (int)c->lanes.size();
         HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
         for (int i = 0; i < nl; ++i) {
             yolo2_hip_ctx *l = c->lanes[i];
+            const uint64_t first = (uint64_t)c->lane_first[i];
             HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
-            const int rc = yolo2_hip_run_batch_int16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
-                                                     region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(int16_t), final_q,
+            const int rc = yolo2_hip_run_batch_int16(l, frames_dev + first * YOLO2_FRAME_ELEMS * sizeof(float), l->batch,
+                                                     region_dev + first * YOLO2_REGION_ELEMS * sizeof(int16_t), final_q,
                                                      l->lane_stream);
             if (rc) return rc;
             HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
@@ -1450,8 +1461,9 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
     if (!c || !out) return fail(YOLO2_ERROR, "null argument");
     if (layer_idx < 0 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
     if (c->laned) {
-        const int half = c->batch / (int)c->lanes.size();
-        return yolo2_hip_debug_layer_output(c->lanes[frame / half], layer_idx, frame % half, out, cap, out_elems);
+        int li = (int)c->lanes.size() - 1;
+        while (li > 0 && frame < c->lane_first[li]) --li;
+        return yolo2_hip_debug_layer_output(c->lanes[li], layer_idx, frame - c->lane_first[li], out, cap, out_elems);
     }
     const LayerDesc &l = kNet[layer_idx];
     if (l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
