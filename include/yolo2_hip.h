@@ -200,6 +200,8 @@ int yolo2_hip_layer_times_ms(yolo2_hip_ctx *ctx, float *ms32 /* [32] */);
  * several concurrent launches and one's idle tail is filled by the others (+4-6 % frames/s at batch 64).
  * Returns the lane count (1 = none).  Per-layer times and launch geometry then describe lane 0's launches. */
 int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
+/* The same for the fp16 path (two half-batch lanes from batch 64; known after the first run_batch_fp16). */
+int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *ctx);
 
 /* Launch geometry of the conv kernel family, for the roofline report.  pixels_per_lane = 0 means
  * the layer runs the split-K kernel (64/S pixels x S K-splits per wavefront, partial clamp-affine

@@ -23,7 +23,8 @@ for r in tail:
     agg[name].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in agg.values())
 span = int(tail[-1]["End_Timestamp"]) - int(tail[0]["Start_Timestamp"])
-print(f"# timed steps only: {steps} steps x {D} dispatches; sum of kernel durations {tot/1e6/steps:.3f} ms/step, "
-      f"first start to last end {span/1e6/steps:.3f} ms/step (launches of the lanes overlap)")
+print(f"# timed steps only: the last {steps} x {D} dispatches (D = shortest period of the dispatch sequence: one pass, or one lane's "
+      f"pass where the lanes issue identical sequences); sum of kernel durations {tot/1e6/steps:.3f} ms per period, "
+      f"first start to last end {span/1e6/steps:.3f} ms per period (the lanes' launches overlap)")
 for name, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    print(f"{name[:70]:70s} launches/step={len(v)//steps:3d} avg_us={sum(v)/len(v)/1e3:9.2f} min_us={min(v)/1e3:9.2f} max_us={max(v)/1e3:9.2f} pct={100*sum(v)/tot:6.2f}")
+    print(f"{name[:70]:70s} launches/period={len(v)//steps:3d} avg_us={sum(v)/len(v)/1e3:9.2f} min_us={min(v)/1e3:9.2f} max_us={max(v)/1e3:9.2f} pct={100*sum(v)/tot:6.2f}")

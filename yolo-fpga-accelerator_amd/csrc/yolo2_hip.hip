@@ -675,6 +675,7 @@ struct yolo2_hip_ctx {
     // +4 % frames/s at batch 64.  A lane is a child context that shares the parent's weights.
     std::vector<yolo2_hip_ctx *> lanes;
     std::vector<int> lane_first;       // first frame of each lane within the batch
+    std::vector<yolo2_hip_ctx *> f16_lanes;   // fp16 path: two half-batch lanes (share wh / biasf / w0f)
     bool is_lane = false, laned = false;
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -808,9 +809,12 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
     if (c->lane_stream) (void)hipStreamDestroy(c->lane_stream);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);
+    c->f16_lanes.clear();
     if (c->is_lane) {   // packed weights and biases belong to the parent
         c->wpk = nullptr;
         c->bias_pk = nullptr;
+        c->wh = nullptr; c->biasf = nullptr; c->w0f = nullptr; c->wf32 = nullptr; c->bf32 = nullptr;
     }
     free_f16_activations(c);
     if (c->wh) (void)hipFree(c->wh);
@@ -1291,6 +1295,7 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
 }
 
 extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? (int)c->lanes.size() : 1; }
+extern "C" int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *c) { return c && !c->f16_lanes.empty() ? (int)c->f16_lanes.size() : 1; }
 
 extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
 {
@@ -1306,6 +1311,7 @@ extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
     }
     c->prof = enable != 0;
     c->prof_runs = 0;  // (re)start the averaging window
+    if (!c->f16_lanes.empty()) return yolo2_hip_set_profiling(c->f16_lanes[0], enable);   // fp16 lanes: lane 0 is reported
     return YOLO2_SUCCESS;
 }
 
@@ -1313,6 +1319,7 @@ extern "C" int yolo2_hip_layer_times_ms(yolo2_hip_ctx *c, float *ms32)
 {
     if (!c || !ms32) return fail(YOLO2_ERROR, "null argument");
     if (c->laned) return yolo2_hip_layer_times_ms(c->lanes[0], ms32);
+    if (c->prof_runs == 0 && !c->f16_lanes.empty()) return yolo2_hip_layer_times_ms(c->f16_lanes[0], ms32);
     if (c->prof_runs == 0) return fail(YOLO2_ERROR, "no profiled run yet");
     const int n = (int)std::min<long>(c->prof_runs, yolo2_hip_ctx::kProfSlots);
     for (int i = 0; i < 32; ++i) ms32[i] = 0.f;
@@ -1629,6 +1636,8 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
             btot += npad;
             ord++;
         }
+    for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);   // they alias the buffers that are about to be replaced
+    c->f16_lanes.clear();
     if (c->wh) (void)hipFree(c->wh);
     if (c->biasf) (void)hipFree(c->biasf);
     c->wh = nullptr;
@@ -1799,9 +1808,43 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     if (!frames_dev || !region_dev) return fail(YOLO2_ERROR, "null buffer address");
     if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
     HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    hipStream_t st = (hipStream_t)stream;
+    // Two half-batch lanes like the int16 path: the big-tile kernels run one workgroup per CU and a layer is only
+    // 2-3 generations of workgroups, so a second stream's launches fill the last, partly empty generation.
+    if (!c->is_lane && batch >= 64 && batch % 2 == 0 && !getenv("YOLO2_F16_NO_LANES")) {
+        if (c->f16_lanes.empty()) {
+            if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
+            for (int i = 0; i < 2; ++i) {
+                yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
+                if (!l) return fail(YOLO2_ERROR, "out of host memory");
+                l->device = c->device;
+                l->is_lane = true;
+                l->wh = c->wh; l->biasf = c->biasf; l->w0f = c->w0f;
+                memcpy(l->wh_off, c->wh_off, sizeof(c->wh_off));
+                memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
+                l->f16_loaded = true;
+                c->f16_lanes.push_back(l);
+                if (hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) != hipSuccess ||
+                    hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess)
+                    return fail(YOLO2_ERROR, "fp16 lane: stream / event creation failed");
+            }
+            if (c->prof) (void)yolo2_hip_set_profiling(c->f16_lanes[0], 1);
+        }
+        const int half = batch / 2;
+        HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
+        for (int i = 0; i < 2; ++i) {
+            yolo2_hip_ctx *l = c->f16_lanes[i];
+            HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
+            const int rc = yolo2_hip_run_batch_fp16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
+                                                    region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(float), l->lane_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
+            HIP_TRY(hipStreamWaitEvent(st, l->ev_join, 0), YOLO2_ERROR);
+        }
+        return YOLO2_SUCCESS;
+    }
     int rc = ensure_f16_batch(c, batch);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
     const int B = batch;
     hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
     if (ev) (void)hipEventRecord(ev[0], st);

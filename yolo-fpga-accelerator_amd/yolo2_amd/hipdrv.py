@@ -30,7 +30,7 @@ EXPORTS = [
     "yolo2_hip_conv_launch_info", "yolo2_strip_int16_layer_pad", "yolo2_weight_len", "yolo2_bias_len",
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
-    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path", "yolo2_hip_run_frame_fp32_host",
+    "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path", "yolo2_hip_run_frame_fp32_host", "yolo2_hip_num_lanes_fp16",
 ]
 
 
@@ -353,6 +353,9 @@ class Yolo2Hip:
         ms = np.zeros(32, dtype=np.float32)
         check(lib().yolo2_hip_layer_times_ms(self._h, ms.ctypes.data_as(C.c_void_p)), "yolo2_hip_layer_times_ms")
         return ms
+
+    def num_lanes_fp16(self) -> int:
+        return int(lib().yolo2_hip_num_lanes_fp16(self._h))
 
     def conv_launch_info(self, ord_: int):
         v = [C.c_int(0) for _ in range(5)]
