@@ -567,6 +567,23 @@ def test_fp32_whole_network_bit_exact_vs_reference_fixture():
     ctx.close()
 
 
+def test_fp16_lanes_batch64_consistent():
+    """From batch 64 the fp16 pass runs as two half-batch lanes on internal streams (fork/join on the caller's
+    stream, here the default stream of the synchronous host entry): every frame must come out exactly as it
+    does alone - per-output summation order does not depend on the frame's position in the batch."""
+    model = synth.SynthModel(seed=1)
+    frames = np.concatenate([synth.frames(300 + k, 1) for k in range(4)] * 16)    # 64 frames, period 4
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    small = ctx.run_batch_fp16_host(frames[:4])
+    assert ctx.num_lanes_fp16() == 1
+    big = ctx.run_batch_fp16_host(frames)
+    assert ctx.num_lanes_fp16() == 2
+    for k in (0, 1, 2, 3, 30, 33, 63):
+        assert np.array_equal(big[k], small[k % 4]), k
+    ctx.close()
+
+
 def test_fp16_path_errors():
     ctx = hipdrv.Yolo2Hip(0)
     with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):

@@ -1287,10 +1287,12 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
             for (auto &e : c->extra[i])
                 plan_conv(e, tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0), (kNet[i].n + 3) / 4, atoi(fp));
         }
+        HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);   // (the tensors' zero fills ran on the null stream)
         return YOLO2_SUCCESS;
     }
     const char *at = getenv("YOLO2_AUTOTUNE");
     if (!(at && at[0] == '0')) return autotune(c);
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
     return YOLO2_SUCCESS;
 }
 
@@ -1798,6 +1800,9 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
     c->h_out[24] = c->h_cat;
     c->h_out[27] = c->h_cat;
     c->f16_batch = B;
+    // the zero fills above run on the null stream; the pass may be enqueued on a non-blocking stream (the lanes'
+    // are), which does not order itself behind it
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
     return YOLO2_SUCCESS;
 }
 
