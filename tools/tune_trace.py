@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""Prints set_batch's autotune timings (YOLO2_VERBOSE) for batch 1: every tile shape / split-K shape per layer (GPU box)."""
 import os, sys
 sys.path.insert(0, "yolo-fpga-accelerator_amd")
 from yolo2_amd import hipdrv, synth
