@@ -74,7 +74,7 @@ def _ref_forward_one(orclib, model, frame):
 
 
 def cpu_baseline(model, frames, gpu_regions):
-    """Times the CPU side on a bounded sample (TWO frames, ~13 s) and checks the GPU result against it.
+    """Times the CPU side on a bounded sample (~7 s) and checks the GPU result against it.
     Preferred: the reference itself, compiled from its own sources (oracle/_ref), driving every
     conv and maxpool layer through its YOLO2_FPGA exactly as yolov2_hls_ps does, single thread
     (the reference is not re-entrant).  Fallback: our C restatement (oracle/liboracle.so)."""
@@ -82,22 +82,21 @@ def cpu_baseline(model, frames, gpu_regions):
     n = len(frames)
     if orclib.have_ref():
         t0 = time.perf_counter()
-        regions = [_ref_forward_one(orclib, model, f) for f in frames]
+        regions = [_ref_forward_one(orclib, model, frames[0])]      # ONE frame (about 6.5 s): keeps the default run short
         dt = time.perf_counter() - t0
-        out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
-               "sample": f"{n} frames: 23 conv + 5 maxpool layers each through the reference's own YOLO2_FPGA "
+        out = {"value": 1 / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+               "sample": "1 frame: 23 conv + 5 maxpool layers through the reference's own YOLO2_FPGA "
                          "(oracle/_ref, built from the reference sources), single thread, weights in memory",
-               "seconds_per_frame": dt / n}
+               "seconds_per_frame": dt}
     else:
         orclib.oracle().orc_set_threads(1)
         t0 = time.perf_counter()
-        regions = [orclib.forward_i16(model, f)[0] for f in frames]
+        regions = [orclib.forward_i16(model, frames[0])[0]]
         dt = time.perf_counter() - t0
-        out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{n} frames through oracle/yolo2_oracle.c (bit-exact C restatement), single thread",
-               "seconds_per_frame": dt / n}
-    out["gpu_matches_cpu_bit_exact"] = bool(all(np.array_equal(np.asarray(r).reshape(-1), g.reshape(-1))
-                                                for r, g in zip(regions, gpu_regions)))
+        out = {"value": 1 / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+               "sample": "1 frame through oracle/yolo2_oracle.c (bit-exact C restatement), single thread",
+               "seconds_per_frame": dt}
+    out["gpu_matches_cpu_bit_exact"] = bool(np.array_equal(np.asarray(regions[0]).reshape(-1), gpu_regions[0].reshape(-1)))
     # the same work on every host core this process may use.  The reference is not
     # re-entrant (function-local statics), so this leg is the re-entrant C restatement, OpenMP over
     # output channels + AVX2 rows; bit-compared with the single-thread result above.
@@ -108,38 +107,101 @@ def cpu_baseline(model, frames, gpu_regions):
     mt = [orclib.forward_i16(model, f)[0] for f in frames]
     dt = time.perf_counter() - t0
     out["all_cores"] = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-                        "sample": f"{n} frames through oracle/yolo2_oracle.c, {cores} OpenMP threads",
-                        "matches_single_thread": bool(all(np.array_equal(np.asarray(a).reshape(-1), np.asarray(b).reshape(-1))
-                                                          for a, b in zip(mt, regions)))}
+                        "sample": f"{n} frames (first and last of the batch) through oracle/yolo2_oracle.c, {cores} OpenMP threads",
+                        "matches_single_thread_reference": bool(np.array_equal(np.asarray(mt[0]).reshape(-1), np.asarray(regions[0]).reshape(-1))),
+                        "gpu_matches_bit_exact": bool(all(np.array_equal(np.asarray(a).reshape(-1), g.reshape(-1))
+                                                          for a, g in zip(mt, gpu_regions)))}
     return out
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources: ties a committed PMC measurement to the build it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
 
 
 def hbm_traffic_per_launch(ks, batch):
     """PMC counters cannot be collected from inside this process: tools/traffic.sh runs this same
     command under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, gfx950 x2 correction on
-    FETCH_SIZE, checked on k_maxpool2's known byte count) and the result is committed under profiles/.
-    Autotune may pick another pixels-per-lane instantiation per run, so the figure is the mean over all
-    launches of the conv kernel with this kernel size (30 of 3x3, 18 of 1x1 per step)."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    FETCH_SIZE, checked on a kernel with a known byte count) and commits the result under profiles/ together
+    with the hash of the kernel sources it was measured on.  A file measured on other sources, another batch or
+    another lane count is NOT reported (traffic: null + the reason) - a stale number is worse than none.
+    Scope: mean over all launches of the conv kernel with this kernel size."""
     try:
-        doc = json.load(open(path))
-        if doc["batch"] != batch:
-            return None, None
-        return doc["kernels"][f"y2::k_conv_i16<KS={ks},...>"]["hbm_bytes_per_launch"], "profiles/r01_hbm_traffic.json (tools/traffic.sh)"
-    except (OSError, KeyError, ValueError):
-        return None, None
+        doc = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+    except (OSError, ValueError):
+        return None, f"{TRAFFIC_FILE} not present"
+    if doc.get("batch") != batch:
+        return None, f"{TRAFFIC_FILE} was measured at batch {doc.get('batch')}"
+    if doc.get("kernel_source_hash") != kernel_source_hash():
+        return None, f"{TRAFFIC_FILE} was measured on other kernel sources ({doc.get('kernel_source_hash')}): re-run tools/traffic.sh"
+    try:
+        return doc["kernels"][f"y2::k_conv_i16<KS={ks},...>"]["hbm_bytes_per_launch"], f"{TRAFFIC_FILE} (tools/traffic.sh)"
+    except KeyError:
+        return None, f"{TRAFFIC_FILE} holds no entry for KS={ks}"
 
 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 
 
+def fp16_record(ctx, B, steps, dt, layer_ms, world=1):
+    """Roofline objects of the fp16 MFMA path from one timed run: `dt` seconds for `steps` passes over B frames per GPU,
+    layer_ms = the library's per-layer hipEvent times of lane 0."""
+    lanes = ctx.num_lanes_fp16()     # 2: every layer is two concurrent half-batch launches; the hipEvents time lane 0's
+    Bl = B // lanes
+    conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
+    halo = [l for l in net.CONVS if l.size == 3 and l.w <= 52 and l.n % 128 == 0 and l.c % 64 == 0]
+    halo_ms = float(sum(layer_ms[l.idx] for l in halo))
+    halo_flops = 2.0 * Bl * sum(l.size * l.size * l.c * l.n * l.out_h * l.out_w for l in halo)
+    halo_launch_ach = halo_flops / (halo_ms * 1e-3) / 1e12      # one launch of lane 0 (shares the chip with lane 1's)
+    halo_ach = halo_launch_ach * lanes                          # chip level: `lanes` such launches run concurrently
+    chip_ach = 2.0 * net.macs_per_frame() * B / (dt / steps) / 1e12
+    return {
+        "value": world * B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16",
+        "config": {"workload": f"YOLOv2 fp16 416x416 batch={B} per GPU, MFMA implicit-GEMM conv (fp32 accumulate)",
+                   "batch_per_gpu": B, "global_batch": B * world, "lanes": lanes, "frames_per_launch": Bl},
+        # dominant kernel: k_conv_f16_halo (3x3 layers at <= 52x52 with >= 128 output channels; selection rule of
+        # yolo2_hip_run_batch_fp16) - its layers' FLOPs / their hipEvent time; whole_pass = all conv layers (incl. fused pools)
+        "roofline": {"bound": "mfma", "kernel": "k_conv_f16_halo", "launches_per_step": len(halo), "layers": [l.idx for l in halo],
+                     "avg_launch_ms": halo_ms / len(halo), "achieved": halo_ach, "peak": MFMA_PEAK_TFLOPS,
+                     "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "algorithmic_flops_per_launch": halo_flops / len(halo), "concurrent_launches": lanes,
+                     "achieved_per_launch": halo_launch_ach,
+                     "note": "achieved = concurrent_launches x (algorithmic FLOPs of one launch / its mean duration): the lanes run the "
+                             "same layer side by side and share the chip; whole_pass is measured from the wall time of the step"},
+        # chip level, independent of how the lanes' launches overlap: all conv FLOPs of the step / wall time of the step
+        "whole_pass": {"scope": "all conv FLOPs of one step (both lanes) / ms_per_step", "achieved": chip_ach, "unit": "TFLOP/s",
+                       "frac": chip_ach / MFMA_PEAK_TFLOPS},
+        "layer_ms": [round(float(x), 4) for x in layer_ms], "conv_ms_per_step": conv_ms,
+    }
+
+
+def fp16_error_vs_fp32(model, frame, gpu_region, threads):
+    """Max |error| of the fp16 region tensor against the fp32 oracle (bit-exact restatement of the reference's fp32 path)."""
+    import orclib
+    orclib.oracle().orc_set_threads(threads)
+    t0 = time.perf_counter()
+    ref = orclib.forward_f32(model, frame)
+    return float(np.abs(gpu_region.reshape(-1) - ref).max()), time.perf_counter() - t0
+
+
 def bench_fp16(args, world, rank, local_rank, dev):
-    """configs[3]: YOLOv2 fp16 MFMA path.  Same protocol as the int16 bench; weights are uploaded
-    by every rank itself from the seeded generator (203 MB fp32 -> fp16 on the device)."""
+    """configs[3]: YOLOv2 fp16 MFMA path.  Same protocol as the int16 bench; rank 0 builds the fp32 weight set and ONE
+    broadcast (the same one the int16 bench uses) puts it on every GPU."""
     B = args.batch
-    model = synth.SynthModel(seed=1)
+    model = synth.SynthModel(seed=1) if rank == 0 else None
+    wf, bf = ydist.broadcast_model_f32(model, dev)
     ctx = hipdrv.Yolo2Hip(local_rank)
-    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    ctx.load_weights_fp32(wf.cpu().numpy(), bf.cpu().numpy())
+    del wf, bf
     lo, hi = ydist.shard_range(B * world, rank, world)
     frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
     region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
@@ -150,7 +212,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -163,59 +225,79 @@ def bench_fp16(args, world, rank, local_rank, dev):
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     layer_ms = ctx.layer_times_ms()
     if rank == 0:
-        fps = world * B * args.steps / dt
-        conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
-        lanes = ctx.num_lanes_fp16()     # 2: every layer is two concurrent half-batch launches; the hipEvents time lane 0's
-        Bl = B // lanes
-        flops = 2.0 * net.macs_per_frame() * Bl
-        ach = flops / (conv_ms * 1e-3) / 1e12
-        halo = [l for l in net.CONVS if l.size == 3 and l.w <= 52 and l.n % 128 == 0 and l.c % 64 == 0]
-        halo_ms = float(sum(layer_ms[l.idx] for l in halo))
-        halo_flops = 2.0 * Bl * sum(l.size * l.size * l.c * l.n * l.out_h * l.out_w for l in halo)
-        halo_launch_ach = halo_flops / (halo_ms * 1e-3) / 1e12      # one launch of lane 0 (shares the chip with lane 1's)
-        halo_ach = halo_launch_ach * lanes                          # chip level: `lanes` such launches run concurrently
-        chip_ach = 2.0 * net.macs_per_frame() * B / (dt / args.steps) / 1e12
-        result = {
-            "metric": "YOLOv2 fp16 416x416 frames/sec", "value": fps, "unit": "frames/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"YOLOv2 fp16 416x416 batch={B} per GPU, MFMA implicit-GEMM conv (fp32 accumulate)",
-                       "batch_per_gpu": B, "global_batch": B * world, "lanes": lanes, "frames_per_launch": Bl},
-            # dominant kernel (with lanes: per launch of lane 0, which overlaps lane 1's launches, so these rates are a lower bound): k_conv_f16_halo (3x3 layers at <= 52x52 with >= 128 output channels; selection rule of
-            # yolo2_hip_run_batch_fp16) - its layers' FLOPs / their hipEvent time; whole_pass = all conv layers (incl. fused pools)
-            "roofline": {"bound": "mfma", "kernel": "k_conv_f16_halo", "launches_per_step": len(halo), "layers": [l.idx for l in halo],
-                         "avg_launch_ms": halo_ms / len(halo), "achieved": halo_ach, "peak": MFMA_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                         "algorithmic_flops_per_launch": halo_flops / len(halo), "concurrent_launches": lanes,
-                         "achieved_per_launch": halo_launch_ach,
-                         "note": "achieved = concurrent_launches x (algorithmic FLOPs of one launch / its mean duration): the lanes run the "
-                                 "same layer side by side and share the chip; whole_pass is measured from the wall time of the step"},
-            # chip level, independent of how the lanes' launches overlap: all conv FLOPs of the step / wall time of the step
-            "whole_pass": {"scope": "all conv FLOPs of one step (both lanes) / ms_per_step", "achieved": chip_ach, "unit": "TFLOP/s",
-                           "frac": chip_ach / MFMA_PEAK_TFLOPS},
-            "layer_ms": [round(float(x), 4) for x in layer_ms], "conv_ms_per_step": conv_ms,
-        }
+        rec = fp16_record(ctx, B, args.steps, dt, layer_ms, world)
+        result = {"metric": "YOLOv2 fp16 416x416 frames/sec", "value": rec["value"], "unit": "frames/s", "n_gpus": world,
+                  "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic"}
+        result.update({k: rec[k] for k in ("config", "roofline", "whole_pass", "layer_ms", "conv_ms_per_step")})
         if world == 1 and not args.no_cpu_baseline:
-            import orclib
-            orclib.oracle().orc_set_threads(1)
-            t0 = time.perf_counter()
-            ref = orclib.forward_f32(model, frames[0].cpu().numpy())
-            cdt = time.perf_counter() - t0
-            err = float(np.abs(region[0].cpu().numpy().reshape(-1) - ref).max())
+            err, cdt = fp16_error_vs_fp32(model, frames[0].cpu().numpy(), region[0].cpu().numpy(), 1)
             result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
                                       "sample": "1 frame through oracle/yolo2_oracle.c fp32 (bit-exact restatement of the reference's fp32 path), single thread",
                                       "seconds_per_frame": cdt, "gpu_max_abs_err_vs_cpu": err}
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def sub_fp16_b256(model, dev, steps=5, warmup=2):
+    """configs[3] under the driver's clock: YOLOv2 fp16 at batch 256 on the MFMA path, as a sub-record of the default line."""
+    B = 256
+    ctx = hipdrv.Yolo2Hip(dev.index or 0)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    base = synth.frames(7, 8)                                   # 8 distinct frames tiled to 256 (the generator is CPU-bound)
+    frames = torch.from_numpy(base).to(dev).repeat(B // 8, 1, 1, 1).contiguous()
+    region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(warmup):
+        ctx.run_batch_fp16_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    ctx.set_profiling(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_batch_fp16_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    rec = fp16_record(ctx, B, steps, dt, ctx.layer_times_ms())
+    rec["warmup"] = warmup
+    threads = min(16, len(os.sched_getaffinity(0)))
+    err, cdt = fp16_error_vs_fp32(model, base[0], region[0].cpu().numpy(), threads)
+    rec["max_abs_err_vs_fp32_oracle"] = err
+    rec["error_check"] = f"frame 0 against oracle/yolo2_oracle.c fp32 on {threads} threads ({cdt:.1f} s); the region tensor spans about +-4.7"
+    assert torch.equal(region[0], region[B - 8]), "fp16 path: the same frame gave different results at different batch positions"
+    ctx.close()
+    return rec
+
+
+def sub_latency_b1(ctx, frames, region, dev, n=30):
+    """configs[1] under the driver's clock: one frame per call, one host sync per frame (device-resident in and out)."""
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_batch(1)
+    split = [l.idx for l in net.CONVS if ctx.conv_launch_info(l.ord)["pixels_per_lane"] == 0]
+    for _ in range(3):
+        ctx.run_batch_ptr(frames.data_ptr(), 1, region.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        ctx.run_batch_ptr(frames.data_ptr(), 1, region.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return {"metric": "YOLOv2 INT16 416x416 single-frame latency", "value": ts[len(ts) // 2], "unit": "ms/frame", "higher_is_better": False,
+            "min_ms": ts[0], "p90_ms": ts[int(0.9 * (len(ts) - 1))], "frames": n, "frames_per_s": 1e3 / ts[len(ts) // 2],
+            "config": {"workload": "YOLOv2 INT16 416x416 batch=1, one host sync per frame, frame and region tensor device-resident"},
+            "split_k_layers": split,
+            "note": "split_k_layers run k_conv_i16_splitk (the saturating chain split four or eight ways, clamp-affine maps combined "
+                    "with wavefront shuffles); chosen per layer by set_batch's timing"}
 
 
 def main():
@@ -225,6 +307,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frames per GPU per step (configs[2]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub-records", action="store_true",
+                    help="skip the latency_b1 (configs[1]) and fp16_b256 (configs[3]) sub-records of the default line")
     ap.add_argument("--precision", choices=["int16", "fp16"], default="int16",
                     help="int16 = the headline bit-exact path; fp16 = MFMA implicit-GEMM path (configs[3], use --batch 256)")
     args = ap.parse_args()
@@ -349,15 +433,26 @@ def main():
                          "traffic_scope": f"mean over the {len(fam)} conv{key[0]}x{key[0]} launches per lane and step (autotune may change the "
                                           "pixels-per-lane instantiation between runs); L2-to-fabric bytes, Infinity Cache hits included",
                          "algorithmic_bytes_per_launch_same_scope": fam_alg,
-                         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"]},
+                         "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
+                         "binds": False,
+                         "note": "BASELINE.json asks for the HBM fraction of the int16 path; by construction it is a few per cent "
+                                 "(SURVEY.md 8d): the path is integer-VALU-issue bound, see binding_roofline"},
+            "binding_roofline": "valu_roofline",
             "valu_roofline": valu,
             "layer_ms": [round(float(x), 4) for x in layer_ms],
             "conv_ms_per_step": conv_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
-            idx = [0, B - 1]    # one frame of each lane
+            idx = [0, B - 1]    # first frame of the first lane, last frame of the last
             result["cpu_baseline"] = cpu_baseline(model, [frames[i].cpu().numpy() for i in idx],
                                                   [region[i].cpu().numpy() for i in idx])
+        if world == 1 and not args.no_sub_records:
+            # configs[1] and configs[3] under the same clock as the headline: ~10 s together
+            r0 = region[0].clone()
+            result["latency_b1"] = sub_latency_b1(ctx, frames, region, dev)
+            result["latency_b1"]["matches_batched_result_bit_exact"] = bool(torch.equal(region[0], r0))
+            ctx.close()
+            result["fp16_b256"] = sub_fp16_b256(model, dev)
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

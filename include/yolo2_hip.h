@@ -53,6 +53,21 @@ int  yolo2_is_busy(void);                            /* yolo2_accel_linux.h:43-4
 int  yolo2_is_done(void);                            /* :49-53 */
 int  yolo2_wait_for_completion(uint32_t timeout_ms); /* :55-61 */
 
+/* yolo2_get_status / yolo2_read_reg / yolo2_write_reg (yolo2_accel_linux.h:57-61, 123-134).  The
+ * reference exposes the HLS IP's AXI-Lite register file (offsets: linux_app/include/yolo2_config.h:
+ * 36-71).  Here it is a 4 KiB shadow register file with the same offsets: the per-layer calls latch
+ * their addresses and scalars into it exactly like yolo2_accel_linux.c:446-505 writes them, AP_CTRL
+ * (offset 0) reads ap_done|ap_idle|ap_ready (0x0e) while the device is idle and ap_start (0x01)
+ * while a layer is in flight, and writing ap_start to AP_CTRL runs the layer the registers describe
+ * (conv for LayerType 0, maxpool for 1) with the Q values of yolo2_set_q_values(), blocking.
+ * All three return 0 / do nothing before yolo2_accel_init(), like the reference. */
+uint32_t yolo2_get_status(void);
+uint32_t yolo2_read_reg(uint32_t offset);
+void     yolo2_write_reg(uint32_t offset, uint32_t value);
+/* Per-layer calls (conv + maxpool) served since yolo2_accel_init(): the reference's layer loop
+ * (linux_app/src/yolo2_inference.c:763-910) makes 28 per frame. */
+long yolo2_hip_driver_calls(void);
+
 /* yolo2_execute_conv_layer (yolo2_accel_linux.h:70-99).  Same 27 arguments and meaning as
  * YOLO2_FPGA with LayerType 0.  input/output are [C][H][W8] int16, weight is the layer's
  * slice of weights_reorg_int16 (blocks of TM x TN x K*K), beta the layer's int16 biases.
@@ -85,11 +100,32 @@ int yolo2_execute_conv_layer_f32(uint64_t input_addr, uint64_t output_addr, uint
 
 /* Buffers: dma_buffer_manager.h:94-139.  ptr is CPU-visible, phys_addr GPU-visible; both
  * name the same mapped pinned pages, so flush/invalidate only have to order, not copy. */
+#ifndef DMA_BUFFER_MANAGER_H   /* the reference's own header may be included first: same types */
 typedef struct {
     void *ptr;
     size_t size;
     uint64_t phys_addr;
 } memory_buffer_t;
+/* dma_buffer_t (dma_buffer_manager.h:24-30): fd is -1 and device_name "hip-pinned" here */
+typedef struct {
+    void *virt_addr;
+    uint64_t phys_addr;
+    size_t size;
+    int fd;
+    char device_name[64];
+} dma_buffer_t;
+#endif
+/* dma_buffer_init / dma_buffer_cleanup (dma_buffer_manager.h:32-42; called by the reference's main,
+ * linux_app/src/main.c:572,1301): init checks that a HIP device is present (the udmabuf check of
+ * dma_buffer_manager.c:137-182), cleanup frees every buffer still allocated (:184-192).
+ * dma_buffer_alloc .. dma_buffer_get_phys (:44-92): the udmabuf-level interface under memory_allocate_*. */
+int      dma_buffer_init(void);
+void     dma_buffer_cleanup(void);
+int      dma_buffer_alloc(size_t size, dma_buffer_t *buffer);
+void     dma_buffer_free(dma_buffer_t *buffer);
+void     dma_buffer_sync_for_device(dma_buffer_t *buffer, size_t offset, size_t size);
+void     dma_buffer_sync_for_cpu(dma_buffer_t *buffer, size_t offset, size_t size);
+uint64_t dma_buffer_get_phys(dma_buffer_t *buffer, size_t offset);
 int      memory_allocate_ddr(size_t size, size_t alignment, memory_buffer_t *buffer);
 void     memory_free_ddr(memory_buffer_t *buffer);
 int      memory_allocate_weights(size_t size, memory_buffer_t *buffer);
@@ -184,7 +220,8 @@ int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *ctx, const float *frames, int b
 
 /* Copies layer `layer_idx`'s output of frame `frame` from the last run into the reference's
  * [C][H][W8] int16 layout (pad columns zero) -- the yolov2_region_*_hw.txt style parity hook
- * (SURVEY.md section 4).  out_elems receives C*H*W8. */
+ * (SURVEY.md section 4).  out_elems receives C*H*W8.  layer_idx -1 = the quantised network input
+ * (input quantise of yolo2_model.cpp:257-273), [3][416][416]. */
 int yolo2_hip_debug_layer_output(yolo2_hip_ctx *ctx, int layer_idx, int frame, int16_t *out,
                                  size_t capacity_elems, size_t *out_elems);
 

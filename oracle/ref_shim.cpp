@@ -66,6 +66,26 @@ int ref_yolov2_hls_ps(const char *cfg_path, const float *input, float *region_pr
 
 // ---- host logic of the reference (src/core/*.cpp), for parity tests of our own C++ host
 
+// load_image_stb (src/core/yolo_image.cpp:167-189): decodes a JPEG/PNG with the reference's vendored stb and
+// returns the decoded pixels as interleaved RGB bytes (the exact inverse of its data[src]/255. conversion) plus
+// the CHW float image it builds from them.  Returns w*h*3, or -1 when the buffers are too small.
+long ref_load_image_u8(const char *path, int *w, int *h, unsigned char *rgb, float *chw, long cap_elems)
+{
+    image im = load_image_stb(const_cast<char *>(path), 3);
+    *w = im.w; *h = im.h;
+    const long n = (long)im.w * im.h * 3;
+    if (n > cap_elems) { free_image(im); return -1; }
+    for (int k = 0; k < 3; ++k)
+        for (int j = 0; j < im.h; ++j)
+            for (int i = 0; i < im.w; ++i) {
+                const float v = im.data[i + im.w * j + im.w * im.h * k];
+                rgb[k + 3 * i + 3 * im.w * j] = (unsigned char)(v * 255.f + 0.5f);
+            }
+    std::memcpy(chw, im.data, sizeof(float) * n);
+    free_image(im);
+    return n;
+}
+
 // letterbox_image (src/core/yolo_image.cpp:148-165) on a CHW float image
 void ref_letterbox(const float *chw, int w, int h, int c, int nw, int nh, float *out)
 {

@@ -219,13 +219,92 @@ def gen_host():
     print("wrote host.npz")
 
 
+def gen_dog():
+    """configs[0] (C1) on the reference's own example image: examples/test_images/dog.jpg decoded by the
+    compiled reference (load_image_stb: its vendored stb), letterboxed by its letterbox_image, run through its
+    yolov2_hls_ps at both precisions, boxes by its get_network_boxes + do_nms_sort at the CLI defaults
+    (NMS 0.45 like src/models/yolov2/yolov2_main.cpp:36-38; threshold 0.05 so that the synthetic weights leave rows to compare).  Stored: decoded RGB bytes, the
+    letterboxed frame's checksum, both region tensors, both detection row sets.  Data only."""
+    import ctypes
+    import hashlib
+    path = b"/root/reference/examples/test_images/dog.jpg"
+    rh = orclib.ref_host()
+    rh.ref_load_image_u8.restype = ctypes.c_long
+    w, h = ctypes.c_int(0), ctypes.c_int(0)
+    cap = 4096 * 4096 * 3
+    rgb = np.zeros(cap, dtype=np.uint8)
+    chw = np.zeros(cap, dtype=np.float32)
+    n = rh.ref_load_image_u8(path, ctypes.byref(w), ctypes.byref(h), rgb.ctypes.data_as(ctypes.c_void_p),
+                             chw.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(cap))
+    assert n == w.value * h.value * 3, n
+    W, H = w.value, h.value
+    rgb = rgb[:n].reshape(H, W, 3).copy()
+    chw = chw[:n].reshape(3, H, W).copy()
+    # the stored bytes reproduce the reference's float image exactly
+    assert np.array_equal((rgb.transpose(2, 0, 1).astype(np.float32) / np.float32(255)).view(np.uint32), chw.view(np.uint32))
+    frame = np.zeros((3, 416, 416), dtype=np.float32)
+    rh.ref_letterbox(np.ascontiguousarray(chw), W, H, 3, 416, 416, frame)
+    out = {"rgb": rgb, "frame_sha256": np.frombuffer(hashlib.sha256(frame.tobytes()).digest(), dtype=np.uint8)}
+    model = synth.SynthModel(seed=1)
+    raw, proc = run_ref_fullnet(model, frame, int16=True)
+    qf = int(model.act_q[23])
+    ri = np.rint(raw * (1 << qf)).astype(np.int64)
+    assert np.all(np.abs(ri * 2.0 ** -qf - raw) <= 1e-7 * np.maximum(1.0, np.abs(raw)))
+    out["i16/region_raw_i16"] = ri.astype(np.int16)
+    out["i16/final_q"] = np.int32(qf)
+    rawf, procf = run_ref_fullnet(model, frame, int16=False)
+    out["f32/region_raw_f32"] = rawf.astype(np.float32)
+    for tag, rr in (("i16", ri.astype(np.float32) * np.float32(2.0 ** -qf)), ("f32", rawf.astype(np.float32))):
+        p2 = np.zeros(425 * 169, dtype=np.float32)
+        rows = np.zeros((845, 85), dtype=np.float32)
+        nb = rh.ref_detect(REF_CFG.encode(), np.ascontiguousarray(rr), W, H, 0.05, 0.45, p2, rows, 845)
+        assert nb == 845
+        out[f"{tag}/detect_rows"] = orclib.canon_rows(rows)
+        out[f"{tag}/detect_params"] = np.array([W, H, 0.05, 0.45], dtype=np.float64)
+        print("dog", tag, "rows kept", len(out[f"{tag}/detect_rows"]))
+    np.savez_compressed(os.path.join(HERE, "dog.npz"), **out)
+    print("wrote dog.npz", rgb.shape)
+
+
+def gen_refapp():
+    """Expected region tensor for tests/test_gpu_ref_app.py: the reference's complete Linux application
+    (oracle/_ref/yolo2_linux = linux_app/src/*.c linked against libyolo2_hip.so) is run there on a 416x416 PPM,
+    for which its loader's letterbox is the identity and the frame is exactly bytes/255.f
+    (linux_app/src/yolo2_image_loader.c:35-80,125-243); here the compiled reference's CPU path produces what it
+    must print."""
+    img = refapp_image()
+    frame = (img.transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+    out = {}
+    for qname, kw in Q_SETS.items():
+        model = synth.SynthModel(seed=1, **kw)
+        raw, _ = run_ref_fullnet(model, frame, int16=True)
+        qf = int(model.act_q[23])
+        ri = np.rint(raw * (1 << qf)).astype(np.int64)
+        assert np.all(np.abs(ri * 2.0 ** -qf - raw) <= 1e-7 * np.maximum(1.0, np.abs(raw)))
+        out[f"{qname}/region_raw_i16"] = ri.astype(np.int16)
+        out[f"{qname}/final_q"] = np.int32(qf)
+        print("refapp", qname, ri.min(), ri.max())
+    np.savez_compressed(os.path.join(HERE, "refapp.npz"), **out)
+    print("wrote refapp.npz")
+
+
+def refapp_image():
+    """416x416 RGB bytes from the seeded frame generator (smooth blocks so that a JPEG-free PPM is all we need)."""
+    f = synth.frames(seed=31, count=1)[0]                       # float [3][416][416] in [0,1)
+    return np.clip(np.floor(f * 256.0), 0, 255).astype(np.uint8).transpose(1, 2, 0).copy()
+
+
 if __name__ == "__main__":
     if not orclib.have_ref():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` in the build container")
-    what = sys.argv[1:] or ["kats", "fullnet", "host"]
+    what = sys.argv[1:] or ["kats", "fullnet", "host", "dog", "refapp"]
     if "kats" in what:
         gen_kats()
     if "fullnet" in what:
         gen_fullnet()
     if "host" in what:
         gen_host()
+    if "dog" in what:
+        gen_dog()
+    if "refapp" in what:
+        gen_refapp()

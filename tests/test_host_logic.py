@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     L = ctypes.CDLL(hipdrv.LIB_PATH)     # loads without a GPU; no compute call is made here
     hdr = open(os.path.join(ROOT, "include", "yolo2_hip.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b((?:yolo2|memory)_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:yolo2|memory|dma_buffer)_[a-z0-9_]+)\s*\(", hdr))
     declared |= {"yolo2_weight_len", "yolo2_bias_len"}
     assert declared == set(hipdrv.EXPORTS), declared ^ set(hipdrv.EXPORTS)
     for name in declared:

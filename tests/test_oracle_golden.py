@@ -113,3 +113,57 @@ def test_fullnet_fp32_matches_reference():
     proc = np.zeros_like(rf)
     orclib.oracle().orc_region_forward(rf, proc)
     assert np.array_equal(proc, FULL["f32/std/region_proc_f32"])
+
+
+# ------------------------------------------------------------------ configs[0] on the reference's example image
+
+DOG = np.load(orclib.os.path.join(orclib.ROOT, "tests", "golden", "dog.npz"))
+REFAPP = np.load(orclib.os.path.join(orclib.ROOT, "tests", "golden", "refapp.npz"))
+
+
+def dog_frame():
+    """dog.jpg as the compiled reference decoded it (bytes), through OUR host letterbox (pinned to the
+    reference's letterbox_image by the frame checksum stored with the fixture)."""
+    import hashlib
+    rgb = DOG["rgb"]
+    h, w, _ = rgb.shape
+    chw = np.ascontiguousarray(rgb.transpose(2, 0, 1).astype(np.float32) / np.float32(255))
+    frame = np.zeros((3, 416, 416), dtype=np.float32)
+    orclib.host().y2h_letterbox(chw, w, h, 3, 416, 416, frame)
+    assert hashlib.sha256(frame.tobytes()).digest() == DOG["frame_sha256"].tobytes(), "host letterbox differs from the reference's"
+    return frame
+
+
+def test_c1_dog_int16_and_fp32_oracle_vs_reference():
+    """configs[0]: the oracle reproduces the region tensors the compiled reference computed from dog.jpg,
+    int16 bit-exact and fp32 bit-exact, and the host post-processing reproduces its detection rows."""
+    frame = dog_frame()
+    model = synth.SynthModel(seed=1)
+    orclib.oracle().orc_set_threads(8)
+    ri, rf, q = orclib.forward_i16(model, frame)
+    assert q == int(DOG["i16/final_q"]) and np.array_equal(ri, DOG["i16/region_raw_i16"])
+    f32 = orclib.forward_f32(model, frame)
+    assert np.array_equal(f32.view(np.uint32), DOG["f32/region_raw_f32"].view(np.uint32))
+    for tag, raw in (("i16", ri.astype(np.float32) * np.float32(2.0 ** -q)), ("f32", f32)):
+        W, H, thresh, nms = DOG[f"{tag}/detect_params"]
+        proc = np.zeros(425 * 169, dtype=np.float32)
+        orclib.host().y2h_region_forward(np.ascontiguousarray(raw), proc)
+        rows = np.zeros((845, 85), dtype=np.float32)
+        orclib.host().y2h_boxes_nms(proc, int(W), int(H), float(thresh), float(nms), rows, 845)
+        assert np.array_equal(orclib.canon_rows(rows), DOG[f"{tag}/detect_rows"]), tag
+
+
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_refapp_fixture_oracle(qset):
+    """The frame the reference's Linux app builds from the 416x416 test image is bytes/255.f; the oracle on it
+    equals what the compiled reference computed (the fixture tests/test_gpu_ref_app.py checks the app against)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", orclib.os.path.join(orclib.ROOT, "tests", "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    img = mg.refapp_image()
+    frame = img.transpose(2, 0, 1).astype(np.float32) / np.float32(255)
+    model = synth.SynthModel(seed=1, **mg.Q_SETS[qset])
+    orclib.oracle().orc_set_threads(8)
+    ri, _, q = orclib.forward_i16(model, frame)
+    assert q == int(REFAPP[f"{qset}/final_q"]) and np.array_equal(ri, REFAPP[f"{qset}/region_raw_i16"])

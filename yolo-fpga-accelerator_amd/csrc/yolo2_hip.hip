@@ -329,8 +329,21 @@ struct DriverState {
         size_t size;
     };
     std::vector<HostBuf> hostbufs;
+    uint32_t regs[1024] = {0};   // shadow of the HLS IP's 4 KiB AXI-Lite register file (yolo2_config.h:36-71 offsets)
+    long calls = 0;              // per-layer calls served since yolo2_accel_init
 };
 DriverState g_drv;
+
+// register offsets of the HLS IP (linux_app/include/yolo2_config.h:36-71)
+enum : uint32_t {
+    R_AP_CTRL = 0x00, R_INPUT = 0x10, R_OUTPUT = 0x1c, R_WEIGHT = 0x28, R_BETA = 0x34, R_IFM = 0x40, R_OFM = 0x48,
+    R_KSIZE = 0x50, R_KSTRIDE = 0x58, R_IN_W = 0x60, R_IN_H = 0x68, R_OUT_W = 0x70, R_OUT_H = 0x78, R_PAD = 0x80,
+    R_ISNL = 0x88, R_ISBN = 0x90, R_TM = 0x98, R_TN = 0xa0, R_TR = 0xa8, R_TC = 0xb0, R_OFM_BOUND = 0xb8,
+    R_MLOOPS = 0xc0, R_MLOOPS_A1 = 0xc8, R_LTYPE = 0xd0,
+    AP_START = 1u << 0, AP_DONE = 1u << 1, AP_IDLE = 1u << 2, AP_READY = 1u << 3,
+};
+inline void reg_set64(uint32_t off, uint64_t v) { g_drv.regs[off / 4] = (uint32_t)v; g_drv.regs[off / 4 + 1] = (uint32_t)(v >> 32); }
+inline uint64_t reg_get64(uint32_t off) { return (uint64_t)g_drv.regs[off / 4] | ((uint64_t)g_drv.regs[off / 4 + 1] << 32); }
 
 int ensure(void **p, size_t *cap, size_t need)
 {
@@ -354,8 +367,8 @@ int sync_with_timeout(hipStream_t st, uint32_t timeout_ms)
         hipError_t e = hipStreamQuery(st);
         if (e == hipSuccess) return YOLO2_SUCCESS;
         if (e != hipErrorNotReady) return fail(YOLO2_ERROR, "stream error: %s", hipGetErrorString(e));
-        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
-        if (ms > (long long)timeout_ms) return fail(YOLO2_TIMEOUT, "layer did not finish within %u ms", timeout_ms);
+        const auto us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (us > (long long)timeout_ms * 1000) return fail(YOLO2_TIMEOUT, "layer did not finish within %u ms", timeout_ms);
     }
 }
 
@@ -401,14 +414,24 @@ extern "C" int yolo2_accel_init(void)
     HIP_TRY(hipSetDevice(g_drv.device), YOLO2_INIT_ERROR);
     if (!g_drv.bound) HIP_TRY(hipMalloc((void **)&g_drv.bound, 4 * sizeof(int)), YOLO2_MMAP_ERROR);   // [max sum, max sum (1 block), max |w|, scale byte]
     g_drv.inited = true;
+    g_drv.calls = 0;
+    memset(g_drv.regs, 0, sizeof(g_drv.regs));
     return YOLO2_SUCCESS;
+}
+
+// Device binding of the driver tier: every entry runs on the device chosen at init, whatever thread calls it.
+static bool drv_ready_locked()
+{
+    return g_drv.inited && hipSetDevice(g_drv.device) == hipSuccess;
 }
 
 extern "C" void yolo2_accel_cleanup(void)
 {
     std::lock_guard<std::mutex> lk(g_drv.mu);
     if (!g_drv.inited) return;
+    (void)hipSetDevice(g_drv.device);
     (void)hipDeviceSynchronize();
+    if (getenv("YOLO2_VERBOSE")) fprintf(stderr, "[yolo2_hip] driver served %ld layer calls\n", g_drv.calls);
     for (void *p : {g_drv.in_items, g_drv.out_items, g_drv.wpk, g_drv.bias_pk, (void *)g_drv.bound})
         if (p) (void)hipFree(p);
     g_drv.in_items = g_drv.out_items = g_drv.wpk = g_drv.bias_pk = nullptr;
@@ -419,11 +442,33 @@ extern "C" void yolo2_accel_cleanup(void)
 
 extern "C" void yolo2_set_q_values(int32_t qw, int32_t qa_in, int32_t qa_out, int32_t qb)
 {
+    std::lock_guard<std::mutex> lk(g_drv.mu);
     g_drv.qw = qw; g_drv.qa_in = qa_in; g_drv.qa_out = qa_out; g_drv.qb = qb;
 }
-extern "C" int yolo2_is_busy(void) { return hipStreamQuery(nullptr) == hipErrorNotReady ? 1 : 0; }
-extern "C" int yolo2_is_done(void) { return hipStreamQuery(nullptr) == hipSuccess ? 1 : 0; }
-extern "C" int yolo2_wait_for_completion(uint32_t timeout_ms) { return sync_with_timeout(nullptr, timeout_ms); }
+// yolo2_accel_linux.c:179-196: before init the reference reports "not busy" / "done"
+extern "C" int yolo2_is_busy(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return 0;
+    return hipStreamQuery(nullptr) == hipErrorNotReady ? 1 : 0;
+}
+extern "C" int yolo2_is_done(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return 1;
+    return hipStreamQuery(nullptr) == hipSuccess ? 1 : 0;
+}
+extern "C" int yolo2_wait_for_completion(uint32_t timeout_ms)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    return sync_with_timeout(nullptr, timeout_ms);
+}
+extern "C" long yolo2_hip_driver_calls(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    return g_drv.calls;
+}
 
 extern "C" int yolo2_hip_alloc(size_t bytes, uint64_t *dev_addr)
 {
@@ -471,12 +516,15 @@ extern "C" int memory_allocate_ddr(size_t size, size_t alignment, memory_buffer_
 extern "C" void memory_free_ddr(memory_buffer_t *buffer)
 {
     if (!buffer || !buffer->ptr) return;
+    bool tracked = false;
     {
         std::lock_guard<std::mutex> lk(g_drv.mu);
         auto &v = g_drv.hostbufs;
+        const size_t before = v.size();
         v.erase(std::remove_if(v.begin(), v.end(), [&](const DriverState::HostBuf &b) { return b.host == buffer->ptr; }), v.end());
+        tracked = v.size() != before;
     }
-    (void)hipHostFree(buffer->ptr);
+    if (tracked) (void)hipHostFree(buffer->ptr);   // (a buffer dma_buffer_cleanup already released is only forgotten)
     buffer->ptr = nullptr;
     buffer->size = 0;
     buffer->phys_addr = 0;
@@ -499,6 +547,59 @@ extern "C" uint64_t memory_get_phys_addr(void *virt_addr)
 extern "C" void memory_flush_cache(void *addr, size_t size) { (void)addr; (void)size; __sync_synchronize(); }
 extern "C" void memory_invalidate_cache(void *addr, size_t size) { (void)addr; (void)size; (void)hipDeviceSynchronize(); }
 
+// dma_buffer_manager.h:32-92, the udmabuf-level interface.  "udmabuf present" becomes "a HIP device is present";
+// a buffer is mapped pinned host memory like memory_allocate_ddr's (fd -1, device name "hip-pinned").
+extern "C" int dma_buffer_init(void)
+{
+    if (yolo2_hip_device_count() < 1) {
+        (void)fail(-1, "no HIP device available for DMA buffers (the GPU path has no CPU fallback)");
+        return -1;
+    }
+    return 0;
+}
+extern "C" void dma_buffer_cleanup(void)
+{
+    std::vector<DriverState::HostBuf> left;
+    {
+        std::lock_guard<std::mutex> lk(g_drv.mu);
+        left.swap(g_drv.hostbufs);
+    }
+    if (!left.empty()) (void)hipDeviceSynchronize();
+    for (const auto &b : left) (void)hipHostFree(b.host);   // dma_buffer_manager.c:184-192: frees what is still tracked
+}
+extern "C" int dma_buffer_alloc(size_t size, dma_buffer_t *buffer)
+{
+    if (!buffer || size == 0) return -1;
+    const size_t aligned = (size + 4095) & ~(size_t)4095;   // page multiple (dma_buffer_manager.c:232-234)
+    memory_buffer_t mb;
+    if (memory_allocate_ddr(aligned, 4096, &mb) != 0) return -1;
+    memset(buffer, 0, sizeof(*buffer));
+    buffer->virt_addr = mb.ptr;
+    buffer->phys_addr = mb.phys_addr;
+    buffer->size = aligned;
+    buffer->fd = -1;
+    snprintf(buffer->device_name, sizeof(buffer->device_name), "hip-pinned");
+    return 0;
+}
+extern "C" void dma_buffer_free(dma_buffer_t *buffer)
+{
+    if (!buffer || !buffer->virt_addr) return;
+    memory_buffer_t mb{buffer->virt_addr, buffer->size, buffer->phys_addr};
+    memory_free_ddr(&mb);
+    memset(buffer, 0, sizeof(*buffer));
+}
+extern "C" void dma_buffer_sync_for_device(dma_buffer_t *buffer, size_t offset, size_t size)
+{
+    (void)buffer; (void)offset; (void)size;
+    __sync_synchronize();
+}
+extern "C" void dma_buffer_sync_for_cpu(dma_buffer_t *buffer, size_t offset, size_t size)
+{
+    (void)buffer; (void)offset; (void)size;
+    (void)hipDeviceSynchronize();
+}
+extern "C" uint64_t dma_buffer_get_phys(dma_buffer_t *buffer, size_t offset) { return buffer ? buffer->phys_addr + offset : 0; }
+
 // ---- per-layer calls
 
 static int max_abs_i16_dev(const short *dev, int n, int *out)
@@ -511,22 +612,32 @@ static int max_abs_i16_dev(const short *dev, int n, int *out)
     return YOLO2_SUCCESS;
 }
 
-extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
-                                        uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
-                                        int input_w, int input_h, int output_w, int output_h, int padding,
-                                        int is_nl, int is_bn, int tm, int tn, int tr, int tc, int ofm_num_bound,
-                                        int mloopsxTM, int mloops_a1xTM, int layer_type, int qw, int qa_in,
-                                        int qa_out, int qb, uint32_t timeout_ms)
+// The conv call with the driver lock held and the device bound (shared by yolo2_execute_conv_layer and the
+// register-level start, yolo2_write_reg(AP_CTRL, ap_start)).
+static int drv_conv_locked(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr, uint64_t beta_addr, int ifm_num,
+                           int ofm_num, int ksize, int kstride, int input_w, int input_h, int output_w, int output_h,
+                           int padding, int is_nl, int is_bn, int tm, int tn, int tr, int tc, int ofm_num_bound, int mloopsxTM,
+                           int mloops_a1xTM, int layer_type, int qw, int qa_in, int qa_out, int qb, uint32_t timeout_ms)
 {
-    (void)is_bn; (void)ofm_num_bound; (void)mloopsxTM; (void)mloops_a1xTM;  // BN is pre-folded; tiling is internal
-    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
     if (layer_type != 0) return fail(YOLO2_ERROR, "yolo2_execute_conv_layer: layer_type %d is not CONV", layer_type);
     if (!input_addr || !output_addr || !weight_addr || !beta_addr) return fail(YOLO2_ERROR, "null buffer address");
     if (!validate_conv_params(ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w, output_h, padding, tm, tn, tr, tc))
         return fail(YOLO2_ERROR, "conv parameters outside the accelerator's limits");
     if (output_w != (input_w - ksize + 2 * padding) / kstride + 1 || output_h != (input_h - ksize + 2 * padding) / kstride + 1)
         return fail(YOLO2_ERROR, "output size does not match input/kernel/stride/padding");
-    std::lock_guard<std::mutex> lk(g_drv.mu);
+    // yolo2_accel_linux.c:463-466: Q arguments that are all zero leave the latched values in force
+    if (qw != 0 || qa_in != 0 || qa_out != 0 || qb != 0) { g_drv.qw = qw; g_drv.qa_in = qa_in; g_drv.qa_out = qa_out; g_drv.qb = qb; }
+    else { qw = g_drv.qw; qa_in = g_drv.qa_in; qa_out = g_drv.qa_out; qb = g_drv.qb; }
+    // latch the call into the register file like yolo2_accel_linux.c:490-527 writes it
+    reg_set64(R_INPUT, input_addr); reg_set64(R_OUTPUT, output_addr); reg_set64(R_WEIGHT, weight_addr); reg_set64(R_BETA, beta_addr);
+    {
+        const uint32_t offs[19] = {R_IFM, R_OFM, R_KSIZE, R_KSTRIDE, R_IN_W, R_IN_H, R_OUT_W, R_OUT_H, R_PAD, R_ISNL, R_ISBN, R_TM, R_TN,
+                                   R_TR, R_TC, R_OFM_BOUND, R_MLOOPS, R_MLOOPS_A1, R_LTYPE};
+        const int vals[19] = {ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w, output_h, padding, is_nl, is_bn, tm, tn,
+                              tr, tc, ofm_num_bound, mloopsxTM, mloops_a1xTM, layer_type};
+        for (int k = 0; k < 19; ++k) g_drv.regs[offs[k] / 4] = (uint32_t)vals[k];
+    }
+    g_drv.calls++;
     hipStream_t st = nullptr;
     const short *in = (const short *)(uintptr_t)input_addr;
     short *out = (short *)(uintptr_t)output_addr;
@@ -594,20 +705,40 @@ extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_add
     return sync_with_timeout(st, timeout_ms);
 }
 
+extern "C" int yolo2_execute_conv_layer(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
+                                        uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
+                                        int input_w, int input_h, int output_w, int output_h, int padding,
+                                        int is_nl, int is_bn, int tm, int tn, int tr, int tc, int ofm_num_bound,
+                                        int mloopsxTM, int mloops_a1xTM, int layer_type, int qw, int qa_in,
+                                        int qa_out, int qb, uint32_t timeout_ms)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    return drv_conv_locked(input_addr, output_addr, weight_addr, beta_addr, ifm_num, ofm_num, ksize, kstride, input_w, input_h,
+                           output_w, output_h, padding, is_nl, is_bn, tm, tn, tr, tc, ofm_num_bound, mloopsxTM, mloops_a1xTM,
+                           layer_type, qw, qa_in, qa_out, qb, timeout_ms);
+}
+
 extern "C" int yolo2_hip_last_layer_path(void) { return g_drv.last_path; }
 
-extern "C" int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int channels, int ksize,
-                                           int kstride, int input_w, int input_h, int output_w, int output_h,
-                                           int padding, int tm, int tr, int tc, int ofm_num_bound, int mloopsxTM,
-                                           int mloops_a1xTM, uint32_t timeout_ms)
+static int drv_pool_locked(uint64_t input_addr, uint64_t output_addr, int channels, int ksize, int kstride, int input_w,
+                           int input_h, int output_w, int output_h, int padding, int tm, int tr, int tc, int ofm_num_bound,
+                           int mloopsxTM, int mloops_a1xTM, uint32_t timeout_ms)
 {
-    (void)padding;  // forced to 0 by the scheduler (core_scheduler.cpp:72-73)
-    (void)ofm_num_bound; (void)mloopsxTM; (void)mloops_a1xTM;
-    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    // padding is forced to 0 by the scheduler (core_scheduler.cpp:72-73)
     if (!input_addr || !output_addr) return fail(YOLO2_ERROR, "null buffer address");
     if (!validate_conv_params(channels, channels, ksize, kstride, input_w, input_h, output_w, output_h, 0, tm, 0, tr, tc))
         return fail(YOLO2_ERROR, "maxpool parameters outside the accelerator's limits");
-    std::lock_guard<std::mutex> lk(g_drv.mu);
+    // yolo2_accel_linux.c:580-655 latches a pool as LayerType 1 with IFM = OFM = channels, TN = 0
+    reg_set64(R_INPUT, input_addr); reg_set64(R_OUTPUT, output_addr);
+    {
+        const uint32_t offs[19] = {R_IFM, R_OFM, R_KSIZE, R_KSTRIDE, R_IN_W, R_IN_H, R_OUT_W, R_OUT_H, R_PAD, R_ISNL, R_ISBN, R_TM, R_TN,
+                                   R_TR, R_TC, R_OFM_BOUND, R_MLOOPS, R_MLOOPS_A1, R_LTYPE};
+        const int vals[19] = {channels, channels, ksize, kstride, input_w, input_h, output_w, output_h, padding, 0, 0, tm, 0,
+                              tr, tc, ofm_num_bound, mloopsxTM, mloops_a1xTM, 1};
+        for (int k = 0; k < 19; ++k) g_drv.regs[offs[k] / 4] = (uint32_t)vals[k];
+    }
+    g_drv.calls++;
     const int n = channels * output_h * output_w;
     hipLaunchKernelGGL((k_pool_ref<short>), dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, (const short *)(uintptr_t)input_addr,
                        (short *)(uintptr_t)output_addr, channels, ksize, kstride, input_w, input_h, output_w, output_h,
@@ -616,16 +747,62 @@ extern "C" int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_
     return sync_with_timeout(nullptr, timeout_ms);
 }
 
+extern "C" int yolo2_execute_maxpool_layer(uint64_t input_addr, uint64_t output_addr, int channels, int ksize,
+                                           int kstride, int input_w, int input_h, int output_w, int output_h,
+                                           int padding, int tm, int tr, int tc, int ofm_num_bound, int mloopsxTM,
+                                           int mloops_a1xTM, uint32_t timeout_ms)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    return drv_pool_locked(input_addr, output_addr, channels, ksize, kstride, input_w, input_h, output_w, output_h, padding, tm, tr,
+                           tc, ofm_num_bound, mloopsxTM, mloops_a1xTM, timeout_ms);
+}
+
+// Register file (yolo2_accel_linux.c:232-258).  AP_CTRL is synthesised from the stream state; a write of ap_start
+// to it runs the layer the registers describe.
+extern "C" uint32_t yolo2_get_status(void)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return 0;
+    return hipStreamQuery(nullptr) == hipErrorNotReady ? AP_START : (AP_DONE | AP_IDLE | AP_READY);
+}
+extern "C" uint32_t yolo2_read_reg(uint32_t offset)
+{
+    if (offset == R_AP_CTRL) return yolo2_get_status();
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!g_drv.inited || offset >= sizeof(g_drv.regs)) return 0;
+    return g_drv.regs[offset / 4];
+}
+extern "C" void yolo2_write_reg(uint32_t offset, uint32_t value)
+{
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked() || offset >= sizeof(g_drv.regs)) return;
+    if (offset != R_AP_CTRL) { g_drv.regs[offset / 4] = value; return; }
+    if (!(value & AP_START)) return;
+    const uint32_t *r = g_drv.regs;
+    auto R = [&](uint32_t off) { return (int)r[off / 4]; };
+    if (R(R_LTYPE) == 0)
+        (void)drv_conv_locked(reg_get64(R_INPUT), reg_get64(R_OUTPUT), reg_get64(R_WEIGHT), reg_get64(R_BETA), R(R_IFM), R(R_OFM),
+                              R(R_KSIZE), R(R_KSTRIDE), R(R_IN_W), R(R_IN_H), R(R_OUT_W), R(R_OUT_H), R(R_PAD), R(R_ISNL), R(R_ISBN),
+                              R(R_TM), R(R_TN), R(R_TR), R(R_TC), R(R_OFM_BOUND), R(R_MLOOPS), R(R_MLOOPS_A1), 0, 0, 0, 0, 0, 0);
+    else if (R(R_LTYPE) == 1)
+        (void)drv_pool_locked(reg_get64(R_INPUT), reg_get64(R_OUTPUT), R(R_IFM), R(R_KSIZE), R(R_KSTRIDE), R(R_IN_W), R(R_IN_H),
+                              R(R_OUT_W), R(R_OUT_H), R(R_PAD), R(R_TM), R(R_TR), R(R_TC), R(R_OFM_BOUND), R(R_MLOOPS),
+                              R(R_MLOOPS_A1), 0);
+    else
+        (void)fail(YOLO2_ERROR, "register start: LayerType %d is not served by the accelerator", R(R_LTYPE));
+}
+
 extern "C" int yolo2_execute_conv_layer_f32(uint64_t input_addr, uint64_t output_addr, uint64_t weight_addr,
                                             uint64_t beta_addr, int ifm_num, int ofm_num, int ksize, int kstride,
                                             int input_w, int input_h, int output_w, int output_h, int padding,
                                             int is_nl, uint32_t timeout_ms)
 {
-    if (!g_drv.inited) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
+    std::lock_guard<std::mutex> lk(g_drv.mu);
+    if (!drv_ready_locked()) return fail(YOLO2_INIT_ERROR, "yolo2_accel_init() has not been called");
     if (!input_addr || !output_addr || !weight_addr || !beta_addr) return fail(YOLO2_ERROR, "null buffer address");
     if (!validate_conv_params(ifm_num, ofm_num, ksize, kstride, input_w, input_h, output_w, output_h, padding, 1, 0, 1, 1))
         return fail(YOLO2_ERROR, "conv parameters outside the accelerator's limits");
-    std::lock_guard<std::mutex> lk(g_drv.mu);
     const int n = ofm_num * output_h * output_w;
     hipLaunchKernelGGL(k_conv_ref_f32, dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, (const float *)(uintptr_t)input_addr,
                        (float *)(uintptr_t)output_addr, (const float *)(uintptr_t)weight_addr,
@@ -1221,6 +1398,7 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     if (const char *e = getenv("YOLO2_LANES")) nl = std::max(1, atoi(e));
     const bool want_lanes = !c->is_lane && nl > 1 && batch >= 8 * nl && !getenv("YOLO2_NO_LANES");
     if (!want_lanes) {
+        if (c->laned) c->batch = 0;   // a laned parent owns no activation tensors: force set_batch_single to allocate
         destroy_lanes(c);
         return set_batch_single(c, batch);
     }
@@ -1299,17 +1477,27 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
 extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? (int)c->lanes.size() : 1; }
 extern "C" int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *c) { return c && !c->f16_lanes.empty() ? (int)c->f16_lanes.size() : 1; }
 
+static int ensure_prof_events(yolo2_hip_ctx *c)
+{
+    if (c->ev_made) return YOLO2_SUCCESS;
+    for (auto &slot : c->ev)
+        for (auto &e : slot) HIP_TRY(hipEventCreate(&e), YOLO2_ERROR);
+    c->ev_made = true;
+    return YOLO2_SUCCESS;
+}
+
 extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
 {
     if (!c) return fail(YOLO2_ERROR, "null ctx");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
     if (c->laned) {   // with lanes the events of lane 0 are reported (its launches overlap lane 1's)
         c->prof = enable != 0;
+        c->prof_runs = 0;
         return yolo2_hip_set_profiling(c->lanes[0], enable);
     }
-    if (enable && !c->ev_made) {
-        for (auto &slot : c->ev)
-            for (auto &e : slot) HIP_TRY(hipEventCreate(&e), YOLO2_ERROR);
-        c->ev_made = true;
+    if (enable) {
+        const int rc = ensure_prof_events(c);
+        if (rc) return rc;
     }
     c->prof = enable != 0;
     c->prof_runs = 0;  // (re)start the averaging window
@@ -1390,8 +1578,12 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
     const int B = batch;
     const float scale = ldexpf(1.0f, c->act_q[0]);
 
+    if (c->prof) {
+        const int rc = ensure_prof_events(c);
+        if (rc) return rc;
+    }
     hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
-    if (ev) (void)hipEventRecord(ev[0], st);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st), YOLO2_ERROR);
     {  // input quantise + pack (yolo2_model.cpp:257-278); its time is booked to layer 0
         const ActGeom &g = c->t_in.g;
         hipLaunchKernelGGL(k_pack_input, dim3(blocks_for((long)B * g.H * g.W, 256)), dim3(256), 0, st, frames, c->t_in.d, B,
@@ -1468,16 +1660,17 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
                                             size_t *out_elems)
 {
     if (!c || !out) return fail(YOLO2_ERROR, "null argument");
-    if (layer_idx < 0 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
+    if (layer_idx < -1 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
     if (c->laned) {
         int li = (int)c->lanes.size() - 1;
         while (li > 0 && frame < c->lane_first[li]) --li;
         return yolo2_hip_debug_layer_output(c->lanes[li], layer_idx, frame - c->lane_first[li], out, cap, out_elems);
     }
-    const LayerDesc &l = kNet[layer_idx];
-    if (l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
-    const Tensor &t = c->t_out[layer_idx];
-    int C = l.type == L_MAX ? l.c : l.n, H = t.g.H, W = t.g.W;
+    // layer -1 = the quantised network input (yolo2_model.cpp:257-273), 3 x 416 x 416
+    const LayerDesc &l = kNet[layer_idx < 0 ? 0 : layer_idx];
+    if (layer_idx >= 0 && l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
+    const Tensor &t = layer_idx < 0 ? c->t_in : c->t_out[layer_idx];
+    int C = layer_idx < 0 ? 3 : (l.type == L_MAX ? l.c : l.n), H = t.g.H, W = t.g.W;
     const short *base = (const short *)t.d;
     if (layer_idx == 24) base += (long)64 * t.g.cg_stride * 4;  // channels 256.. of the concat tensor
     const int W8 = (W + 7) & ~7;
@@ -1665,6 +1858,10 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
         boff += yolo2_bias_len[ord];
         ord++;
     }
+    // the halo-tile kernels use up to the whole 160 KiB of LDS: raise their dynamic-LDS limit on THIS device
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
     hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
@@ -1819,20 +2016,26 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     if (!c->is_lane && batch >= 64 && batch % 2 == 0 && !getenv("YOLO2_F16_NO_LANES")) {
         if (c->f16_lanes.empty()) {
             if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
-            for (int i = 0; i < 2; ++i) {
+            std::vector<yolo2_hip_ctx *> made;   // committed only when both lanes are complete
+            bool ok = true;
+            for (int i = 0; i < 2 && ok; ++i) {
                 yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
-                if (!l) return fail(YOLO2_ERROR, "out of host memory");
+                if (!l) { ok = false; break; }
+                made.push_back(l);
                 l->device = c->device;
                 l->is_lane = true;
                 l->wh = c->wh; l->biasf = c->biasf; l->w0f = c->w0f;
                 memcpy(l->wh_off, c->wh_off, sizeof(c->wh_off));
                 memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
                 l->f16_loaded = true;
-                c->f16_lanes.push_back(l);
-                if (hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) != hipSuccess ||
-                    hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess)
-                    return fail(YOLO2_ERROR, "fp16 lane: stream / event creation failed");
+                ok = hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) == hipSuccess &&
+                     hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess;
             }
+            if (!ok) {
+                for (yolo2_hip_ctx *l : made) yolo2_hip_destroy(l);
+                return fail(YOLO2_ERROR, "fp16 lanes: context / stream / event creation failed");
+            }
+            c->f16_lanes = made;
             if (c->prof) (void)yolo2_hip_set_profiling(c->f16_lanes[0], 1);
         }
         const int half = batch / 2;
@@ -1851,8 +2054,12 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     int rc = ensure_f16_batch(c, batch);
     if (rc) return rc;
     const int B = batch;
+    if (c->prof) {
+        const int prc = ensure_prof_events(c);
+        if (prc) return prc;
+    }
     hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
-    if (ev) (void)hipEventRecord(ev[0], st);
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st), YOLO2_ERROR);
     {   // layers 0+1 fused: conv 3->32 + leaky + 2x2 pool straight from the float frames
         const auto &g = c->h_out[1];
         if (!getenv("YOLO2_F16_NO_MFMA0"))   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
@@ -1916,27 +2123,14 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                     // dense tile: 256 pixels + W+1 on either side, rounded to 8-row groups, + 8 zero rows
                     const int lt_rows = round_up(256 + 2 * (l.w + 1), 8) + 8;
                     const size_t a_bytes = (size_t)2 * lt_rows * 128, fo_bytes = 256 * sizeof(int), cap = 160 * 1024;
-                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes,
-                                 lds128s = a_bytes + (size_t)2 * 128 * 128 + fo_bytes;
+                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes;
                     const bool wide = l.n % 256 == 0 && lds256 <= cap && a_bytes + (size_t)2 * 256 * 128 >= (size_t)256 * 264 * 2 &&
                                       !getenv("YOLO2_F16_NO_WIDE");
                     const bool three = lds128 <= cap;
                     // (the two-buffer 256x128 form that would fit the 104x104 layers runs one workgroup per CU and measured
                     //  6 % slower there than the 128x128 kernel with two: only the shapes below are used)
-                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three) && lds128s <= 2 * cap;
-                    if (fits) {
-                        static bool attr_set = false;
-                        if (!attr_set) {
-                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)cap), YOLO2_ERROR);
-                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)cap), YOLO2_ERROR);
-                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)cap), YOLO2_ERROR);
-                            HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        (int)cap), YOLO2_ERROR);
-                            attr_set = true;
-                        }
+                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three);
+                    if (fits) {   // (the kernels' dynamic-LDS limit was raised for this device in load_weights_fp32)
                         if (wide) {
                             a.n_tiles = l.n / 256;
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
@@ -1946,8 +2140,7 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                                 hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
                         } else {
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
-                            if (three) hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);
-                            else hipLaunchKernelGGL((k_conv_f16_halo<128, 2>), hgrid, dim3(512), lds128s, st, ip, wp, bp, op, a, lt_rows);
+                            hipLaunchKernelGGL((k_conv_f16_halo<128, 3>), hgrid, dim3(512), lds128, st, ip, wp, bp, op, a, lt_rows);   // `fits` without `wide` implies `three`
                         }
                         if (i != 30) cur = &c->h_out[i];
                         ord++;

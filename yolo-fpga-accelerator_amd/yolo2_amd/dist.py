@@ -50,3 +50,18 @@ def broadcast_model(model, device: torch.device, src: int = 0):
         dist.broadcast(q, src)
     wq, bq, aq = unpack_q_tables(q)
     return w, b, wq, bq, aq
+
+
+def broadcast_model_f32(model, device: torch.device, src: int = 0):
+    """fp32 twin (weights_reorg.bin / bias.bin contents) for the fp16 MFMA path: rank `src` holds the model."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if rank == src:
+        w = torch.from_numpy(model.weights_f32()).to(device)
+        b = torch.from_numpy(model.bias_f32()).to(device)
+    else:
+        w = torch.empty(net.N_WEIGHTS, dtype=torch.float32, device=device)
+        b = torch.empty(net.N_BIAS, dtype=torch.float32, device=device)
+    if dist.is_initialized():
+        dist.broadcast(w.view(torch.uint8), src)   # 203,767,168 B
+        dist.broadcast(b.view(torch.uint8), src)
+    return w, b

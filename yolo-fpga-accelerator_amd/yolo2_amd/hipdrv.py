@@ -31,6 +31,9 @@ EXPORTS = [
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
     "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path", "yolo2_hip_run_frame_fp32_host", "yolo2_hip_num_lanes_fp16",
+    "yolo2_get_status", "yolo2_read_reg", "yolo2_write_reg", "yolo2_hip_driver_calls",
+    "dma_buffer_init", "dma_buffer_cleanup", "dma_buffer_alloc", "dma_buffer_free", "dma_buffer_sync_for_device",
+    "dma_buffer_sync_for_cpu", "dma_buffer_get_phys",
 ]
 
 
@@ -111,6 +114,18 @@ def lib():
     L.yolo2_hip_letterbox_u8.argtypes = [u64, i32, i32, i32, u64, i32, i32, vp]
     L.yolo2_hip_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.memory_get_phys_addr.restype = u64
+    L.yolo2_get_status.restype = u32
+    L.yolo2_read_reg.restype = u32
+    L.yolo2_read_reg.argtypes = [u32]
+    L.yolo2_write_reg.argtypes = [u32, u32]
+    L.yolo2_hip_driver_calls.restype = C.c_long
+    L.yolo2_set_q_values.argtypes = [i32] * 4
+    L.dma_buffer_alloc.argtypes = [C.c_size_t, vp]
+    L.dma_buffer_free.argtypes = [vp]
+    L.dma_buffer_get_phys.restype = u64
+    L.dma_buffer_get_phys.argtypes = [vp, C.c_size_t]
+    L.dma_buffer_sync_for_device.argtypes = [vp, C.c_size_t, C.c_size_t]
+    L.dma_buffer_sync_for_cpu.argtypes = [vp, C.c_size_t, C.c_size_t]
     L.memory_get_phys_addr.argtypes = [vp]
     _lib = L
     return L
@@ -334,8 +349,11 @@ class Yolo2Hip:
         return region, q.value
 
     def debug_layer_output(self, layer_idx: int, frame: int = 0) -> np.ndarray:
-        l = net.LAYERS[layer_idx]
-        shape = (l.out_c, l.out_h, w8(l.out_w))
+        if layer_idx < 0:      # the quantised network input
+            shape = (3, 416, 416)
+        else:
+            l = net.LAYERS[layer_idx]
+            shape = (l.out_c, l.out_h, w8(l.out_w))
         out = np.empty(shape, dtype=np.int16)
         n = C.c_size_t(0)
         check(lib().yolo2_hip_debug_layer_output(self._h, layer_idx, frame, out.ctypes.data_as(C.c_void_p),
