@@ -240,6 +240,11 @@ int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 /* The same for the fp16 path (two half-batch lanes from batch 64; known after the first run_batch_fp16). */
 int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *ctx);
 
+/* 1 when conv layer `layer_idx` (0..31) runs fused with the 2x2 max pool after it (k_conv_i16_pool: the
+ * full-resolution tensor is never written, except layer 16's, which also feeds the route), 0 otherwise.
+ * Chosen per batch by set_batch (timed); YOLO2_NO_POOLFUSE=1 disables, YOLO2_POOLFUSE=1 forces it wherever legal. */
+int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *ctx, int layer_idx);
+
 /* Launch geometry of the conv kernel family, for the roofline report.  pixels_per_lane = 0 means
  * the layer runs the split-K kernel (64/S pixels x S K-splits per wavefront, partial clamp-affine
  * maps combined with wavefront shuffles), which set_batch picks for small batches when it times

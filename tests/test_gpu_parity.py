@@ -184,7 +184,10 @@ def test_mapped_host_buffers_like_udmabuf(driver):
 def _diagnose(ctx, model, frame, frame_idx):
     """Layer-by-layer diff against the oracle to localise a mismatch."""
     _, _, _, layers = orclib.forward_i16(model, frame, dump=True)
+    fused = ctx.pool_fused_layers()
     for i in sorted(layers):
+        if i in fused and i != 16:
+            continue          # conv + pool ran as one kernel: that conv's own tensor was never written
         got = ctx.debug_layer_output(i, frame_idx)
         l = net.LAYERS[i]
         if not np.array_equal(got[:, :, :l.out_w], layers[i][:, :, :l.out_w]):
@@ -815,3 +818,68 @@ def test_register_file_and_dma_buffers(driver):
     assert bufs[0].virt_addr is None and L.memory_get_phys_addr(ctypes.c_void_p(bufs[1].virt_addr)) == bufs[1].phys_addr
     L.dma_buffer_cleanup()                        # frees what is still tracked
     assert L.memory_get_phys_addr(ctypes.c_void_p(bufs[1].virt_addr)) == 0
+
+
+@pytest.mark.parametrize("path", [None, "3", "4"])
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_conv_pool_fused(qset, path, monkeypatch):
+    """k_conv_i16_pool forced wherever legal (layers 0, 2, 6, 10, 16): a lane owns a 2x2 pool window, 64 windows per
+    tile in raster order (tiles straddle row pairs and frames at batch 3 and 5), max over the window in the epilogue.
+    Bit-exact against the reference fixture and the oracle; the pooled tensors (layers 1, 3, 7, 11, 17) and layer 16's
+    full-resolution tensor (kept for the route) are compared with the oracle's per-layer dumps; the unfused conv
+    tensors are reported as not materialised."""
+    monkeypatch.setenv("YOLO2_POOLFUSE", "1")
+    if path is not None:
+        monkeypatch.setenv("YOLO2_FORCE_PATH", path)
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 1, 3), synth.frames(fseed, 1)])
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    orclib.oracle().orc_set_threads(16)
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    for batch in (1, 3, 5):
+        region, _ = ctx.run_batch_host(frames[:batch])
+        fused = ctx.pool_fused_layers()
+        # (a layer whose blocks need a 32-bit or 64-bit form - one form-B block of layer 2 with the varq tables - stays unfused)
+        assert set(fused) <= {0, 2, 6, 10, 16} and {0, 6, 10, 16} <= set(fused), fused
+        assert qset != "std" or fused == [0, 2, 6, 10, 16]
+        assert all(ctx.conv_launch_info(net.LAYERS[i].ord)["pixels_per_lane"] == 4 for i in fused)
+        if not np.array_equal(region[0], want):
+            pytest.fail(f"batch {batch}: " + _diagnose(ctx, model, frames[0], 0))
+        if batch == 5:
+            assert np.array_equal(region[4], want)
+            f = 2
+            ri, _, _, layers = orclib.forward_i16(model, frames[f], dump=True)
+            assert np.array_equal(region[f].reshape(-1), ri), _diagnose(ctx, model, frames[f], f)
+            for i in (1, 3, 7, 11, 16, 17):
+                l = net.LAYERS[i]
+                if i - 1 not in fused and i != 16:
+                    continue
+                got = ctx.debug_layer_output(i, f)
+                assert np.array_equal(got[:, :, :l.out_w], layers[i][:, :, :l.out_w]), i
+            with pytest.raises(hipdrv.Yolo2HipError, match="not materialised"):
+                ctx.debug_layer_output(6, 0)
+    ctx.close()
+
+
+def test_conv_pool_fusion_default_and_disabled(monkeypatch):
+    """Default: set_batch times {conv + k_maxpool2} against the fused kernel per layer and keeps the faster; whatever
+    it picks, batch 16 (two lanes) equals the fixture and the unfused run.  YOLO2_NO_POOLFUSE=1 keeps every tensor."""
+    model = synth.SynthModel(seed=1)
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(60, 15)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    r1, _ = ctx.run_batch_host(frames)
+    picked = ctx.pool_fused_layers()
+    assert set(picked) <= {0, 2, 6, 10, 16}
+    assert np.array_equal(r1[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    ctx.close()
+    monkeypatch.setenv("YOLO2_NO_POOLFUSE", "1")
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    r2, _ = ctx.run_batch_host(frames)
+    assert ctx.pool_fused_layers() == []
+    assert np.array_equal(r1, r2)
+    ctx.debug_layer_output(6, 3)
+    ctx.close()

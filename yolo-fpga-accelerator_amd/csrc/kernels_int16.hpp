@@ -43,6 +43,11 @@ struct ConvArgs {
     int xcd_remap;             // 0 = launch order; 1 + log2(Xm): XCDs as an (8/Xm) x Xm grid over (tiles, blocks)
     const int *mb_list;        // optional: blockIdx.y -> output-channel block (a layer whose blocks need
                                // different arithmetic forms is launched once per form); nullptr = identity
+    // conv + leaky + 2x2/2 max pool fused (k_conv_i16_pool): geometry of the pooled destination tensor
+    int nwin;                  // B * (H/2) * (W/2) pool windows
+    int oWp, oPL;              // row pitch / plane size of the pooled tensor (items)
+    long pool_cg_stride;       // items between channel groups of the pooled tensor
+    long pool_base;            // item offset of its channel group 0, incl. lead
 };
 
 // core_compute.cpp:191-197: x<0 ? x/10 (C division, toward zero) : x.  For u in [1,32768]
@@ -450,6 +455,175 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             o.x = (v[0] & 0xffff) | (v[1] << 16);
             o.y = (v[2] & 0xffff) | (v[3] << 16);
             if (valid[p]) dst[fo[p]] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ conv 3x3 + leaky + 2x2/2 max pool, fused
+//
+// Five of the 3x3 convs (layers 0, 2, 6, 10, 16) feed a 2x2 stride-2 max pool (pool_yolo2, core_compute.cpp:266-305),
+// and for four of them the pool is the ONLY consumer: the full-resolution tensor need never reach memory.  Here a lane
+// owns one pool WINDOW = 2 x 2 conv outputs (x 8 channels per wavefront), computes them with exactly the step sequence
+// of k_conv_i16 (same order group -> tap, same saturating chain: bit-exact) and stores max(leaky(.)) - the integer leaky
+// is monotonic, so max and leaky commute exactly.  What changes around the steps:
+//   * a tile = 64 consecutive windows in raster order over (b, oy, ox); the input of all their pixels (+ halo) is still
+//     ONE contiguous run of the flat item layout (whole rows between the first window's top-left halo and the last
+//     window's bottom-right halo), so staging is unchanged;
+//   * the four pixels of a window share a 4 x 4 input patch: 16 ds_read_b64 per channel group feed 36 (pixel, tap) steps
+//     (the 1-pixel-per-lane form reads 9 per 9), fetched ahead of the group's tap loop;
+//   * FULL (layer 16, which also feeds the route to layer 26): the full-resolution tensor is stored as well;
+//   * SINGLE (one input channel group: layer 0): nothing is staged inside the loop, so the staging registers die
+//     after the prologue.
+// MODE 3 / 4 only (packed int16 accumulators); layers whose blocks need another form keep conv + k_maxpool2.
+__device__ __forceinline__ int pkmax16(int a, int b)
+{
+    return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, b)));
+}
+
+template <int MODE, int NST, bool FULL, bool SINGLE = false>
+__global__ __launch_bounds__(256) void k_conv_i16_pool(const int2 *__restrict__ in, int2 *__restrict__ out_full,
+                                                        int2 *__restrict__ out_pool, const int2 *__restrict__ wpk,
+                                                        const short *__restrict__ bias, const ConvArgs a)
+{
+    static_assert(MODE == 3 || MODE == 4, "packed-accumulator forms only");
+    extern __shared__ int2 lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x, yb = blockIdx.y;
+    if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
+    const int mb = a.mb_list ? a.mb_list[yb] : yb;
+    const int OW = a.W >> 1, OHW = (a.H >> 1) * OW;
+    // flat item offset of the top-left pixel of window wq
+    auto win_tl = [&](int wq, int &b, int &oy, int &ox) -> int {
+        b = wq / OHW;
+        const int r = wq - b * OHW;
+        oy = r / OW;
+        ox = r - oy * OW;
+        return b * a.PL + (2 * oy + 1) * a.Wp + 2 * ox;
+    };
+    const int w0 = tile * 64, wlast = min(w0 + 63, a.nwin - 1);
+    int tb, toy, tox;
+    const int f_first = win_tl(w0, tb, toy, tox);
+    const int f_last = win_tl(wlast, tb, toy, tox) + a.Wp + 1;      // bottom-right pixel of the last window
+    const int tile_start = f_first - a.Wp - 1;
+    const int Lt = min(f_last + a.Wp + 1 - tile_start + 1, a.lt_max);
+
+    const int wq = w0 + lane;
+    const bool valid = wq <= wlast;
+    int wb, woy, wox;
+    const int ftl = win_tl(min(wq, wlast), wb, woy, wox);
+    // LDS byte address of patch row r (image rows 2oy-1 .. 2oy+2), column 2ox-1
+    int prow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) prow[r] = (ftl - tile_start + (r - 1) * a.Wp - 1) * 8;
+
+    int acc[4][4];   // [pixel dy*2+dx][channel pair]
+    {
+        const short *bp = bias + mb * 32 + wave * 8;
+        int pk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int b2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int b = bp[2 * j + h];
+                b2[h] = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
+            }
+            pk[j] = (b2[0] & 0xffff) | (b2[1] << 16);   // the host proved |shifted bias| <= 32767
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[p][j] = pk[j];
+    }
+    int r_vgpr = a.round;
+    asm volatile("" : "+v"(r_vgpr));
+    const int s = a.shift;
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    const int2 *src = in + kLead + tile_start;
+    const int2 *wq_p = wpk + ((long)mb * a.CGin * 9 * 32 + wave * 8);
+
+    int2 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) stage[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) lds[i] = stage[k];
+    }
+    __syncthreads();
+
+    for (int cg = 0; cg < a.CGin; ++cg) {
+        const bool more = !SINGLE && cg + 1 < a.CGin;     // wave-uniform
+        if (more) {
+            src += a.in_cg_stride;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int i = tid + k * 256;
+                if (i < Lt) stage[k] = src[i];
+            }
+        }
+        const char *tl = lds_b + (cg & 1) * a.lt_max * 8;
+        int2 patch[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) patch[r][c] = *reinterpret_cast<const int2 *>(tl + prow[r] + c * 8);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            int2 w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) w[m] = wq_p[tap * 32 + m];   // wave-uniform: scalar loads
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int2 x = patch[(p >> 1) + tap / 3][(p & 1) + tap % 3];
+                if (MODE == 4) {
+                    stepD8(acc[p][0], acc[p][1], acc[p][2], acc[p][3], x, w, r_vgpr, 0x07060302);
+                } else {
+                    stepC4(acc[p][0], acc[p][1], x, w[0], w[1], w[2], w[3], r_vgpr, s);
+                    stepC4(acc[p][2], acc[p][3], x, w[4], w[5], w[6], w[7], r_vgpr, s);
+                }
+            }
+        }
+        if (more) {
+            int2 *nxt = lds + ((cg + 1) & 1) * a.lt_max;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int i = tid + k * 256;
+                if (i < Lt) nxt[i] = stage[k];
+            }
+        }
+        wq_p += 9 * 32;
+        __syncthreads();
+    }
+
+    // epilogue: max over the window on packed pairs, then the integer leaky (monotonic: commutes with max)
+    int mx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mx[j] = pkmax16(pkmax16(acc[0][j], acc[1][j]), pkmax16(acc[2][j], acc[3][j]));
+    const int fpool = wb * a.oPL + (woy + 1) * a.oWp + wox;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const int cgo = mb * 8 + wave * 2 + g;
+        if (cgo >= a.CGout) continue;
+        auto pack4 = [&](int p01, int p23) -> int2 {
+            int v[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = a.leaky ? leaky_i16(v[t]) : v[t];
+            int2 o;
+            o.x = (v[0] & 0xffff) | (v[1] << 16);
+            o.y = (v[2] & 0xffff) | (v[3] << 16);
+            return o;
+        };
+        if (valid) out_pool[a.pool_base + (long)cgo * a.pool_cg_stride + fpool] = pack4(mx[2 * g], mx[2 * g + 1]);
+        if (FULL) {
+            int2 *dst = out_full + a.out_base + (long)cgo * a.out_cg_stride;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (valid) dst[ftl + (p >> 1) * a.Wp + (p & 1)] = pack4(acc[p][2 * g], acc[p][2 * g + 1]);
         }
     }
 }

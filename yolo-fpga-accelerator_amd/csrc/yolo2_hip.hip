@@ -167,6 +167,7 @@ struct ConvPlan {
     int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
     int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
     int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
+    int pool_fused = 0;        // conv + leaky + 2x2 pool in one kernel (k_conv_i16_pool): 1 = pooled tensor only, 2 = + full tensor
     int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
                                // fewer co-resident workgroups finish sooner each, which shortens the
                                // idle tail of layers that are only a few workgroup-generations long
@@ -239,6 +240,52 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     }
 }
 
+// Upper bound of the LDS tile (items) of k_conv_i16_pool: 64 consecutive pool windows in raster order.  Between the
+// top-left pixels of two consecutive windows the flat offset grows by 2 (same row pair), W + 4 (next row pair) or
+// 2W + 5 (next frame); the tile adds a halo of Wp + 1 on either side and the bottom-right pixel of its last window.
+static int pool_tile_items_bound(const ActGeom &g)
+{
+    const int OW = g.W / 2, OHW = (g.H / 2) * OW;
+    const int wraps = std::min(63, (63 + OW - 1) / OW), frames = std::min(63, (63 + OHW - 1) / OHW);
+    return 126 + wraps * (g.W + 2) + frames * (g.W + 1) + 3 * g.Wp + 4;
+}
+
+// Re-plans a conv launch (already planned by plan_conv for this input geometry) as the fused conv + pool kernel.
+static bool plan_conv_pool(ConvPlan &p, const ActGeom &gin, const ActGeom &gpool, int full)
+{
+    if (p.K != 3 || (p.path != 3 && p.path != 4) || (gin.H & 1) || (gin.W & 1)) return false;
+    const int lt = pool_tile_items_bound(gin);
+    if (lt > 12 * 256) return false;
+    ConvArgs &a = p.args;
+    p.splitk = 0; p.grp = 1; p.P = 4; p.lds_pad = 0;
+    p.pool_fused = full ? 2 : 1;
+    a.lt_max = lt;
+    a.nwin = gin.B * (gin.H / 2) * (gin.W / 2);
+    a.oWp = gpool.Wp; a.oPL = gpool.PL;
+    a.pool_cg_stride = gpool.cg_stride;
+    a.pool_base = kLead;
+    p.lds_bytes = lt * 8 * (gin.CG > 1 ? 2 : 1);
+    p.grid = dim3((a.nwin + 63) / 64, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
+    return true;
+}
+
+template <int MODE, bool FULL>
+static void launch_conv_pool_n(const ConvPlan &p, const int2 *in, int2 *out, int2 *out_pool, const int2 *wpk, const short *bias,
+                               hipStream_t st)
+{
+    const int nst = (p.args.lt_max + 255) / 256;
+#define Y2_POOL(NSTV, SINGLEV) hipLaunchKernelGGL((k_conv_i16_pool<MODE, NSTV, FULL, SINGLEV>), p.grid, dim3(256), p.lds_bytes, st, in, out, out_pool, wpk, bias, p.args)
+    if (p.args.CGin == 1) {   // layer 0: the whole input tile is staged once, up front
+        if (nst <= 4) Y2_POOL(4, true);
+        else Y2_POOL(12, true);
+    } else if (nst <= 2) Y2_POOL(2, false);
+    else if (nst <= 3) Y2_POOL(3, false);
+    else if (nst <= 5) Y2_POOL(5, false);
+    else if (nst <= 8) Y2_POOL(8, false);
+    else Y2_POOL(12, false);
+#undef Y2_POOL
+}
+
 template <int KS, int MODE, int P>
 static void launch_conv_n(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
 {
@@ -265,8 +312,19 @@ static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const in
     }
 }
 
-static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
+static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st,
+                        int2 *out_pool = nullptr)
 {
+    if (p.pool_fused) {   // out_pool: the pooled tensor (the layer after this conv)
+        if (p.path == 4) {
+            if (p.pool_fused == 2) launch_conv_pool_n<4, true>(p, in, out, out_pool, wpk, bias, st);
+            else launch_conv_pool_n<4, false>(p, in, out, out_pool, wpk, bias, st);
+        } else {
+            if (p.pool_fused == 2) launch_conv_pool_n<3, true>(p, in, out, out_pool, wpk, bias, st);
+            else launch_conv_pool_n<3, false>(p, in, out, out_pool, wpk, bias, st);
+        }
+        return;
+    }
     if (p.splitk) {
         const int nst = (p.splitk * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
         const bool pack = p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK");   // form D layers: packed int16 triples
@@ -856,6 +914,9 @@ struct yolo2_hip_ctx {
     bool is_lane = false, laned = false;
     hipStream_t lane_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fuse_pool[32] = {false};      // conv layer i stores the pooled tensor of layer i+1 itself (k_conv_i16_pool)
+    ConvPlan fplan[32];                // the fused launches of those layers (plan / extra keep the unfused ones)
+    std::vector<ConvPlan> fextra[32];
     int path_counts[YOLO2_N_CONV][5];
     int reorg_shift = 0, final_q = 0;
     int batch = 0;
@@ -1356,6 +1417,87 @@ static int autotune(yolo2_hip_ctx *c)
 
 static int set_batch_single(yolo2_hip_ctx *c, int batch);
 
+static void launch_maxpool(const Tensor &tin, const Tensor &tout, int B, hipStream_t st)
+{
+    const ActGeom &gi = tin.g, &go = tout.g;
+    const long n = (long)go.CG * B * go.H * go.W;
+    hipLaunchKernelGGL(k_maxpool2, dim3(blocks_for(n, 256)), dim3(256), 0, st, tin.d, tout.d, go.CG, B, go.H, go.W, gi.Wp, gi.PL,
+                       go.Wp, go.PL);
+}
+
+// Conv layers followed by a 2x2 pool (0, 2, 6, 10, 16) may run as ONE kernel that stores the pooled tensor
+// (k_conv_i16_pool); layer 16 also feeds the route to layer 26, so it stores the full-resolution tensor too.
+// Legal when every launch of the layer runs a packed-accumulator form (C / D).  timed: keep whichever of
+// {conv launches + k_maxpool2, fused launches} is faster on this batch (cold L2, like autotune); otherwise fuse
+// wherever legal.  YOLO2_NO_POOLFUSE=1 disables, YOLO2_POOLFUSE=1 forces it wherever legal.
+static int setup_pool_fusion(yolo2_hip_ctx *c, bool timed, bool default_on)
+{
+    for (bool &f : c->fuse_pool) f = false;
+    if (getenv("YOLO2_NO_POOLFUSE")) return YOLO2_SUCCESS;
+    const char *fe = getenv("YOLO2_POOLFUSE");
+    const bool force = fe && atoi(fe) == 1;
+    if (!default_on && !force) return YOLO2_SUCCESS;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void *flush = nullptr;
+    const size_t flush_bytes = (size_t)64 << 20;
+    if (timed && !force) {
+        HIP_TRY(hipEventCreate(&e0), YOLO2_ERROR);
+        HIP_TRY(hipEventCreate(&e1), YOLO2_ERROR);
+        HIP_TRY(hipMalloc(&flush, flush_bytes), YOLO2_MMAP_ERROR);
+    }
+    int ord = 0;
+    for (int i = 0; i < 31; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const int o = ord++;
+        if (kNet[i + 1].type != L_MAX) continue;
+        const Tensor &tin = i == 0 ? c->t_in : c->t_out[i - 1];
+        const Tensor &tout = c->t_out[i], &tpool = c->t_out[i + 1];
+        const int full = i == 16 ? 1 : 0;
+        ConvPlan fp = c->plan[i];
+        bool ok = plan_conv_pool(fp, tin.g, tpool.g, full);
+        std::vector<ConvPlan> fx;
+        for (const auto &e : c->extra[i]) {
+            ConvPlan fe2 = e;
+            ok = ok && plan_conv_pool(fe2, tin.g, tpool.g, full);
+            fx.push_back(fe2);
+        }
+        if (!ok) continue;
+        c->fplan[i] = fp;
+        c->fextra[i] = fx;
+        if (!timed || force) { c->fuse_pool[i] = true; continue; }
+        const int2 *wp = (const int2 *)(c->wpk + c->wpk_off[o]);
+        const short *bp = c->bias_pk + c->bias_off[o];
+        float best[2] = {1e30f, 1e30f};
+        for (int variant = 0; variant < 2; ++variant)
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
+                (void)hipEventRecord(e0, nullptr);
+                if (variant == 0) {
+                    launch_conv(c->plan[i], tin.d, tout.d, wp, bp, nullptr);
+                    for (const auto &e : c->extra[i]) launch_conv(e, tin.d, tout.d, wp, bp, nullptr);
+                    launch_maxpool(tout, tpool, c->batch, nullptr);
+                } else {
+                    launch_conv(fp, tin.d, tout.d, wp, bp, nullptr, tpool.d);
+                    for (const auto &e : fx) launch_conv(e, tin.d, tout.d, wp, bp, nullptr, tpool.d);
+                }
+                (void)hipEventRecord(e1, nullptr);
+                HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
+                best[variant] = std::min(best[variant], t);
+            }
+        c->fuse_pool[i] = best[1] < best[0];
+        if (getenv("YOLO2_VERBOSE"))
+            fprintf(stderr, "[yolo2_hip] L%d conv+pool: separate %.1f us, fused %.1f us -> %s\n", i, best[0] * 1e3, best[1] * 1e3,
+                    c->fuse_pool[i] ? "fused" : "separate");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (flush) (void)hipFree(flush);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
 static int make_lane(yolo2_hip_ctx *p, yolo2_hip_ctx **out)
 {
     yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
@@ -1466,12 +1608,15 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
                 plan_conv(e, tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0), (kNet[i].n + 3) / 4, atoi(fp));
         }
         HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);   // (the tensors' zero fills ran on the null stream)
-        return YOLO2_SUCCESS;
+        return setup_pool_fusion(c, false, false);      // fixed tile shapes: fusion only on request (YOLO2_POOLFUSE=1)
     }
     const char *at = getenv("YOLO2_AUTOTUNE");
-    if (!(at && at[0] == '0')) return autotune(c);
+    if (!(at && at[0] == '0')) {
+        const int rc = autotune(c);
+        return rc ? rc : setup_pool_fusion(c, true, true);
+    }
     HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
-    return YOLO2_SUCCESS;
+    return setup_pool_fusion(c, false, true);
 }
 
 extern "C" int yolo2_hip_num_lanes(yolo2_hip_ctx *c) { return c && c->laned ? (int)c->lanes.size() : 1; }
@@ -1524,6 +1669,13 @@ extern "C" int yolo2_hip_layer_times_ms(yolo2_hip_ctx *c, float *ms32)
     return YOLO2_SUCCESS;
 }
 
+extern "C" int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *c, int layer_idx)
+{
+    if (!c || layer_idx < 0 || layer_idx > 31 || !c->batch) return 0;
+    if (c->laned) return yolo2_hip_layer_pool_fused(c->lanes[0], layer_idx);
+    return c->fuse_pool[layer_idx] ? 1 : 0;
+}
+
 extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x, int *grid_y, int *block, int *lds_bytes,
                                           int *ppl)
 {
@@ -1533,11 +1685,12 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
     for (int i = 0; i < 32; ++i)
         if (kNet[i].type == L_CONV) {
             if (o == ord) {
-                if (grid_x) *grid_x = c->plan[i].grid.x;
-                if (grid_y) *grid_y = c->plan[i].grid.y;
+                const ConvPlan &pl = c->fuse_pool[i] ? c->fplan[i] : c->plan[i];
+                if (grid_x) *grid_x = pl.grid.x;
+                if (grid_y) *grid_y = pl.grid.y;
                 if (block) *block = 256;
-                if (lds_bytes) *lds_bytes = c->plan[i].lds_bytes;
-                if (ppl) *ppl = c->plan[i].splitk ? 0 : c->plan[i].P;
+                if (lds_bytes) *lds_bytes = pl.lds_bytes;
+                if (ppl) *ppl = pl.splitk ? 0 : pl.P;
                 return YOLO2_SUCCESS;
             }
             o++;
@@ -1596,19 +1749,22 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
         switch (l.type) {
         case L_CONV: {
             const Tensor *tin = i == 26 ? &c->t_out[16] : (i == 29 ? &c->t_cat : cur);
-            launch_conv(c->plan[i], tin->d, c->t_out[i].d, (const int2 *)(c->wpk + c->wpk_off[ord]),
-                        c->bias_pk + c->bias_off[ord], st);
-            for (const auto &e : c->extra[i])   // blocks of this layer that need another arithmetic form
-                launch_conv(e, tin->d, c->t_out[i].d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], st);
+            const int2 *wp = (const int2 *)(c->wpk + c->wpk_off[ord]);
+            const short *bp = c->bias_pk + c->bias_off[ord];
+            if (c->fuse_pool[i]) {   // conv + leaky + pool in one kernel: stores layer i+1's tensor (and layer 16's own)
+                launch_conv(c->fplan[i], tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
+                for (const auto &e : c->fextra[i]) launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
+            } else {
+                launch_conv(c->plan[i], tin->d, c->t_out[i].d, wp, bp, st);
+                for (const auto &e : c->extra[i])   // blocks of this layer that need another arithmetic form
+                    launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st);
+            }
             cur = &c->t_out[i];
             ord++;
             break;
         }
         case L_MAX: {
-            const ActGeom &gi = cur->g, &go = c->t_out[i].g;
-            const long n = (long)go.CG * B * go.H * go.W;
-            hipLaunchKernelGGL(k_maxpool2, dim3(blocks_for(n, 256)), dim3(256), 0, st, cur->d, c->t_out[i].d, go.CG, B, go.H,
-                               go.W, gi.Wp, gi.PL, go.Wp, go.PL);
+            if (!c->fuse_pool[i - 1]) launch_maxpool(*cur, c->t_out[i], B, st);
             cur = &c->t_out[i];
             break;
         }
@@ -1666,6 +1822,8 @@ extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int
         while (li > 0 && frame < c->lane_first[li]) --li;
         return yolo2_hip_debug_layer_output(c->lanes[li], layer_idx, frame - c->lane_first[li], out, cap, out_elems);
     }
+    if (layer_idx >= 0 && c->fuse_pool[layer_idx] && layer_idx != 16)
+        return fail(YOLO2_ERROR, "layer %d's tensor is not materialised: conv + pool run fused (YOLO2_NO_POOLFUSE=1 keeps it)", layer_idx);
     // layer -1 = the quantised network input (yolo2_model.cpp:257-273), 3 x 416 x 416
     const LayerDesc &l = kNet[layer_idx < 0 ? 0 : layer_idx];
     if (layer_idx >= 0 && l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");

@@ -13,7 +13,8 @@ import numpy as np
 from . import net
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libyolo2_hip.so")
+# YOLO2_HIP_LIB: another build of the same library (A/B runs of compile-time kernel variants, tools/ab.sh)
+LIB_PATH = os.environ.get("YOLO2_HIP_LIB") or os.path.join(PKG_DIR, "libyolo2_hip.so")
 
 YOLO2_SUCCESS, YOLO2_ERROR, YOLO2_TIMEOUT, YOLO2_INIT_ERROR, YOLO2_MMAP_ERROR, YOLO2_DMA_ERROR = 0, -1, -2, -3, -4, -5
 
@@ -31,7 +32,7 @@ EXPORTS = [
     "yolo2_hip_num_layers", "yolo2_hip_layer_desc",
     "yolo2_hip_layer_path_counts", "yolo2_hip_run_frames_int16", "yolo2_hip_num_lanes", "yolo2_hip_load_weights_fp32", "yolo2_hip_run_batch_fp16", "yolo2_hip_run_batch_fp16_host",
     "yolo2_hip_letterbox_u8", "yolo2_hip_run_images_u8_host", "yolo2_hip_last_layer_path", "yolo2_hip_run_frame_fp32_host", "yolo2_hip_num_lanes_fp16",
-    "yolo2_get_status", "yolo2_read_reg", "yolo2_write_reg", "yolo2_hip_driver_calls",
+    "yolo2_hip_layer_pool_fused", "yolo2_get_status", "yolo2_read_reg", "yolo2_write_reg", "yolo2_hip_driver_calls",
     "dma_buffer_init", "dma_buffer_cleanup", "dma_buffer_alloc", "dma_buffer_free", "dma_buffer_sync_for_device",
     "dma_buffer_sync_for_cpu", "dma_buffer_get_phys",
 ]
@@ -96,6 +97,7 @@ def lib():
     L.yolo2_hip_load_weights_int16_dev.argtypes = [vp, u64, C.c_size_t, u64, C.c_size_t, vp, i32, vp, i32, vp, i32]
     L.yolo2_hip_layer_path.argtypes = [vp, i32]
     L.yolo2_hip_num_lanes.argtypes = [vp]
+    L.yolo2_hip_layer_pool_fused.argtypes = [vp, i32]
     L.yolo2_hip_run_frames_int16.argtypes = [vp, vp, i32, i32, vp, C.POINTER(i32)]
     L.yolo2_hip_layer_path_counts.argtypes = [vp, i32, C.POINTER(i32)]
     L.yolo2_hip_set_batch.argtypes = [vp, i32]
@@ -363,6 +365,10 @@ class Yolo2Hip:
 
     def num_lanes(self) -> int:
         return lib().yolo2_hip_num_lanes(self._h)
+
+    def pool_fused_layers(self):
+        """Conv layers that run fused with the max pool after them (their full-resolution tensor is not written)."""
+        return [i for i in range(32) if lib().yolo2_hip_layer_pool_fused(self._h, i)]
 
     def set_profiling(self, on: bool):
         check(lib().yolo2_hip_set_profiling(self._h, int(on)), "yolo2_hip_set_profiling")
