@@ -214,6 +214,9 @@ int yolo2_hip_run_frames_int16(yolo2_hip_ctx *ctx, const float *frames, int n_fr
  * fp32 mode, yolo2_model.cpp:422-424).  Validated against the fp32 reference at box tolerance. */
 int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *ctx, const float *weights_reorg, size_t n_weights,
                                 const float *bias, size_t n_bias);
+/* Same, the two blobs already in HBM (e.g. received by the RCCL broadcast below). */
+int yolo2_hip_load_weights_fp32_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_dev, size_t n_weights,
+                                    uint64_t bias_dev, size_t n_bias);
 int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch, uint64_t region_dev,
                              void *stream);
 int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *ctx, const float *frames, int batch, float *region);
@@ -277,6 +280,78 @@ int yolo2_hip_letterbox_u8(uint64_t image_dev, int w, int h, int channels, uint6
 int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *ctx, const uint8_t *const *images, const int *widths,
                                  const int *heights, int channels, int n, int batch,
                                  int16_t *region_host, int *final_q);
+
+/* ------------------------------------------------------- the step after the path, on the GPU
+ *
+ * forward_region_layer + get_network_boxes + do_nms_sort (src/core/yolo_region.cpp:123-236, src/core/yolo_post.cpp:54-85)
+ * for a whole batch, one workgroup per frame, from a region tensor that is already in HBM (the output of
+ * yolo2_hip_run_batch_*).  For the int16 tensor the result is IDENTICAL to the reference host code's: every exp the
+ * reference applies to one of the 65,536 possible values int16 x 2^-Q is a table the host's own libm filled, all other
+ * arithmetic is IEEE +,-,*,/ in the reference's order, the per-class sort is stable like glibc's qsort.  The float entry
+ * (fp16 / fp32 tensors) evaluates exp on the device: within 1 ulp of the host's.
+ *   im_w / im_h [batch]   original image sizes (letterbox correction, relative = 1 like yolov2_main.cpp:310-312)
+ *   dets / counts         optional: (frame, det, class, prob, box) records for every prob > 0 after NMS, in the order
+ *                         the reference prints them (dets in array order, classes inner), cap_per_frame records per frame;
+ *                         counts[f] = records frame f has (may exceed the cap: the surplus is dropped)
+ *   rows / totals         optional: the reference's dets[] array after do_nms_sort, [batch][845][85] =
+ *                         x, y, w, h, objectness, prob[80], and the number of slots in front that hold a candidate
+ *   proc                  optional: l.output of forward_region_layer, [batch][425][13][13]
+ * Synchronous (host buffers out); enqueues on `stream` (NULL = default). */
+typedef struct {
+    int frame, det, cls;
+    float prob, x, y, w, h;
+} yolo2_hip_det;
+int yolo2_hip_postprocess_int16(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, int final_q, const int *im_w,
+                                const int *im_h, float thresh, float nms, yolo2_hip_det *dets, int cap_per_frame,
+                                int *counts, float *rows, int *totals, float *proc, void *stream);
+int yolo2_hip_postprocess_f32(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, const int *im_w, const int *im_h,
+                              float thresh, float nms, yolo2_hip_det *dets, int cap_per_frame, int *counts,
+                              float *rows, int *totals, float *proc, void *stream);
+
+/* ------------------------------------------------------- multi-GPU: frame sharding, one weight broadcast
+ *
+ * SURVEY.md 8(b) "init(device_list) ... load_weights (H2D on rank 0, RCCL broadcast to the rest)", 8(e): frames are
+ * independent, so every GPU holds the whole weight set, frames split into contiguous ranges, and the only collective is
+ * ONE broadcast of the weight blobs at init (ncclBroadcast from librccl.so, RCCL over xGMI; the library is loaded at the
+ * first call of this section, single-GPU users never load it).  Both launch models share that one broadcast routine. */
+
+/* contiguous range [lo, hi) of `rank` among `world` shards of `total` frames; sizes differ by at most one */
+int yolo2_hip_shard_range(int total, int rank, int world, int *lo, int *hi);
+
+/* (a) one process, n devices - the C host's model (yolov2_detect --devices 0,1,...): one context per device, a RCCL
+ * communicator over the list (ncclCommInitAll).  A list that names one device twice rehearses the sharding on a single
+ * GPU: RCCL refuses duplicate devices, so such a list copies device-to-device instead (yolo2_hip_multi_uses_rccl = 0). */
+typedef struct yolo2_hip_multi yolo2_hip_multi;
+int  yolo2_hip_multi_create(const int *devices, int n_devices, yolo2_hip_multi **m);
+void yolo2_hip_multi_destroy(yolo2_hip_multi *m);
+int  yolo2_hip_multi_num_devices(yolo2_hip_multi *m);
+int  yolo2_hip_multi_uses_rccl(yolo2_hip_multi *m);
+yolo2_hip_ctx *yolo2_hip_multi_ctx(yolo2_hip_multi *m, int i);      /* borrowed: for set_batch / profiling / layer_path */
+/* blobs: host -> devices[0] -> ncclBroadcast to the rest -> every context loads its device copy */
+int  yolo2_hip_multi_load_weights_int16(yolo2_hip_multi *m, const int16_t *weights_reorg, size_t n_weights,
+                                        const int16_t *bias, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                        const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q);
+int  yolo2_hip_multi_load_weights_fp32(yolo2_hip_multi *m, const float *weights_reorg, size_t n_weights,
+                                       const float *bias, size_t n_bias);
+/* n_frames host frames -> region tensors, shard i streamed by device i (yolo2_hip_run_frames_int16 / _run_images_u8_host
+ * on its own host thread, chunks of batch_per_device); no data-path collective.  Results do not depend on the device count. */
+int  yolo2_hip_multi_run_frames_int16(yolo2_hip_multi *m, const float *frames, int n_frames, int batch_per_device,
+                                      int16_t *region, int *final_q);
+int  yolo2_hip_multi_run_images_u8_host(yolo2_hip_multi *m, const uint8_t *const *images, const int *widths,
+                                        const int *heights, int channels, int n, int batch_per_device,
+                                        int16_t *region_host, int *final_q);
+
+/* (b) one process per device (torchrun / MPI style; what bench.py --gpus N runs): rank 0 makes the 128-byte id
+ * (ncclGetUniqueId), the launcher hands it to every rank, each rank joins with its context (ncclCommInitRank), then
+ * ALL ranks call the _bcast loader: the root passes the host blobs and Q tables, the others NULL / 0. */
+int  yolo2_hip_rccl_unique_id(void *id128);
+int  yolo2_hip_rccl_init_rank(yolo2_hip_ctx *ctx, int device, const void *id128, int nranks, int rank);
+void yolo2_hip_rccl_finalize(yolo2_hip_ctx *ctx);
+int  yolo2_hip_load_weights_int16_bcast(yolo2_hip_ctx *ctx, const int16_t *weights_reorg, size_t n_weights,
+                                        const int16_t *bias, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                        const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q, int root);
+int  yolo2_hip_load_weights_fp32_bcast(yolo2_hip_ctx *ctx, const float *weights_reorg, size_t n_weights,
+                                       const float *bias, size_t n_bias, int root);
 
 /* ------------------------------------------------------------------- tier 3: helpers */
 

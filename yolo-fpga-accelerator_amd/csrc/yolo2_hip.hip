@@ -44,6 +44,8 @@ static int fail(int code, const char *fmt, ...)
     } while (0)
 
 extern "C" const char *yolo2_hip_last_error(void) { return g_err; }
+// for the library's other translation units (yolo2_multi.hip, yolo2_post.hip): same thread-local message slot
+extern "C" int yolo2_hip_set_error(int code, const char *msg) { return fail(code, "%s", msg ? msg : ""); }
 
 // ---------------------------------------------------------------------------- model tables
 
@@ -956,6 +958,8 @@ extern "C" int yolo2_hip_create(int device, yolo2_hip_ctx **out)
     *out = c;
     return YOLO2_SUCCESS;
 }
+
+extern "C" int yolo2_hip_ctx_device(yolo2_hip_ctx *c) { return c ? c->device : -1; }
 
 static void free_activations(yolo2_hip_ctx *c)
 {
@@ -1970,8 +1974,22 @@ extern "C" int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *c, const uint8_t *con
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind);
+
 extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weights_reorg, size_t n_weights,
                                            const float *bias, size_t n_bias)
+{
+    return load_fp32_common(c, weights_reorg, n_weights, bias, n_bias, hipMemcpyHostToDevice);
+}
+
+extern "C" int yolo2_hip_load_weights_fp32_dev(yolo2_hip_ctx *c, uint64_t weights_reorg_dev, size_t n_weights, uint64_t bias_dev,
+                                               size_t n_bias)
+{
+    return load_fp32_common(c, (const void *)(uintptr_t)weights_reorg_dev, n_weights, (const void *)(uintptr_t)bias_dev, n_bias,
+                            hipMemcpyDeviceToDevice);
+}
+
+static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind)
 {
     if (!c || !weights_reorg || !bias) return fail(YOLO2_ERROR, "null argument");
     if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
@@ -2000,8 +2018,8 @@ extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weight
     HIP_TRY(hipMalloc((void **)&c->biasf, (size_t)btot * 4), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 4), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 4), YOLO2_MMAP_ERROR);
-    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
-    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, kind), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, kind), YOLO2_DMA_ERROR);
     long woff = 0, boff = 0;
     ord = 0;
     for (int i = 0; i < 32; ++i) {

@@ -35,6 +35,11 @@ EXPORTS = [
     "yolo2_hip_layer_pool_fused", "yolo2_get_status", "yolo2_read_reg", "yolo2_write_reg", "yolo2_hip_driver_calls",
     "dma_buffer_init", "dma_buffer_cleanup", "dma_buffer_alloc", "dma_buffer_free", "dma_buffer_sync_for_device",
     "dma_buffer_sync_for_cpu", "dma_buffer_get_phys",
+    "yolo2_hip_load_weights_fp32_dev", "yolo2_hip_postprocess_int16", "yolo2_hip_postprocess_f32",
+    "yolo2_hip_shard_range", "yolo2_hip_multi_create", "yolo2_hip_multi_destroy", "yolo2_hip_multi_num_devices",
+    "yolo2_hip_multi_uses_rccl", "yolo2_hip_multi_ctx", "yolo2_hip_multi_load_weights_int16", "yolo2_hip_multi_load_weights_fp32",
+    "yolo2_hip_multi_run_frames_int16", "yolo2_hip_multi_run_images_u8_host", "yolo2_hip_rccl_unique_id",
+    "yolo2_hip_rccl_init_rank", "yolo2_hip_rccl_finalize", "yolo2_hip_load_weights_int16_bcast", "yolo2_hip_load_weights_fp32_bcast",
 ]
 
 
@@ -116,6 +121,26 @@ def lib():
     L.yolo2_hip_letterbox_u8.argtypes = [u64, i32, i32, i32, u64, i32, i32, vp]
     L.yolo2_hip_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.memory_get_phys_addr.restype = u64
+    pi32 = C.POINTER(i32)
+    L.yolo2_hip_load_weights_fp32_dev.argtypes = [vp, u64, C.c_size_t, u64, C.c_size_t]
+    L.yolo2_hip_postprocess_int16.argtypes = [vp, u64, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
+    L.yolo2_hip_postprocess_f32.argtypes = [vp, u64, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
+    L.yolo2_hip_shard_range.argtypes = [i32, i32, i32, pi32, pi32]
+    L.yolo2_hip_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
+    L.yolo2_hip_multi_destroy.argtypes = [vp]
+    L.yolo2_hip_multi_num_devices.argtypes = [vp]
+    L.yolo2_hip_multi_uses_rccl.argtypes = [vp]
+    L.yolo2_hip_multi_ctx.argtypes = [vp, i32]
+    L.yolo2_hip_multi_ctx.restype = vp
+    L.yolo2_hip_multi_load_weights_int16.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32]
+    L.yolo2_hip_multi_load_weights_fp32.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    L.yolo2_hip_multi_run_frames_int16.argtypes = [vp, vp, i32, i32, vp, pi32]
+    L.yolo2_hip_multi_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, pi32]
+    L.yolo2_hip_rccl_unique_id.argtypes = [vp]
+    L.yolo2_hip_rccl_init_rank.argtypes = [vp, i32, vp, i32, i32]
+    L.yolo2_hip_rccl_finalize.argtypes = [vp]
+    L.yolo2_hip_load_weights_int16_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32, i32]
+    L.yolo2_hip_load_weights_fp32_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i32]
     L.yolo2_get_status.restype = u32
     L.yolo2_read_reg.restype = u32
     L.yolo2_read_reg.argtypes = [u32]
@@ -385,3 +410,142 @@ class Yolo2Hip:
         v = [C.c_int(0) for _ in range(5)]
         check(lib().yolo2_hip_conv_launch_info(self._h, ord_, *[C.byref(x) for x in v]), "conv_launch_info")
         return dict(zip(("grid_x", "grid_y", "block", "lds_bytes", "pixels_per_lane"), (x.value for x in v)))
+
+
+# ------------------------------------------------------------------ post-processing on the GPU
+
+DET_DTYPE = np.dtype([("frame", np.int32), ("det", np.int32), ("cls", np.int32), ("prob", np.float32),
+                      ("x", np.float32), ("y", np.float32), ("w", np.float32), ("h", np.float32)])
+
+
+def postprocess(ctx, region_ptr: int, batch: int, im_w, im_h, thresh: float, nms: float, final_q: int = None, cap: int = 256,
+                want_rows: bool = False, want_proc: bool = False, stream: int = 0):
+    """yolo2_hip_postprocess_int16 (final_q given) / _f32 on a DEVICE region tensor.  Returns a dict with
+    dets (structured array of the records kept), counts, and optionally rows [B][845][85], totals, proc."""
+    iw = np.ascontiguousarray(im_w, dtype=np.int32)
+    ih = np.ascontiguousarray(im_h, dtype=np.int32)
+    assert iw.size == batch and ih.size == batch
+    dets = np.zeros((batch, cap), dtype=DET_DTYPE)
+    counts = np.zeros(batch, dtype=np.int32)
+    rows = np.zeros((batch, 845, 85), dtype=np.float32) if want_rows else None
+    totals = np.zeros(batch, dtype=np.int32)
+    proc = np.zeros((batch, 425 * 169), dtype=np.float32) if want_proc else None
+    vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    if final_q is not None:
+        rc = lib().yolo2_hip_postprocess_int16(ctx._h, region_ptr, batch, int(final_q), vp(iw), vp(ih), thresh, nms, vp(dets), cap,
+                                               vp(counts), vp(rows), vp(totals), vp(proc), C.c_void_p(stream))
+    else:
+        rc = lib().yolo2_hip_postprocess_f32(ctx._h, region_ptr, batch, vp(iw), vp(ih), thresh, nms, vp(dets), cap, vp(counts),
+                                             vp(rows), vp(totals), vp(proc), C.c_void_p(stream))
+    check(rc, "yolo2_hip_postprocess")
+    return {"dets": [dets[f, :min(int(counts[f]), cap)] for f in range(batch)], "counts": counts, "rows": rows, "totals": totals, "proc": proc}
+
+
+# ------------------------------------------------------------------ more than one GPU
+
+def shard_range(total: int, rank: int, world: int):
+    lo, hi = C.c_int(0), C.c_int(0)
+    check(lib().yolo2_hip_shard_range(total, rank, world, C.byref(lo), C.byref(hi)), "yolo2_hip_shard_range")
+    return lo.value, hi.value
+
+
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId (rank 0): 128 bytes the launcher hands to every rank."""
+    buf = (C.c_char * 128)()
+    check(lib().yolo2_hip_rccl_unique_id(buf), "yolo2_hip_rccl_unique_id")
+    return bytes(buf)
+
+
+class _BcastMixin:
+    def rccl_init_rank(self, id128: bytes, nranks: int, rank: int):
+        assert len(id128) == 128
+        check(lib().yolo2_hip_rccl_init_rank(self._h, self.device, C.c_char_p(id128), nranks, rank), "yolo2_hip_rccl_init_rank")
+        self._in_comm = True
+
+    def rccl_finalize(self):
+        if getattr(self, "_in_comm", False):
+            lib().yolo2_hip_rccl_finalize(self._h)
+            self._in_comm = False
+
+    def load_model_bcast(self, model, root: int = 0):
+        """All ranks call this; `model` is the SynthModel on the root rank and None elsewhere.  One ncclBroadcast per blob
+        (the library's own RCCL communicator), then every rank loads its device copy."""
+        if model is not None:
+            w = np.ascontiguousarray(model.weights_i16(), dtype=np.int16)
+            b = np.ascontiguousarray(model.bias_i16(), dtype=np.int16)
+            wq, bq, aq = (np.ascontiguousarray(a, dtype=np.int32) for a in (model.weight_q, model.bias_q, model.act_q))
+            vp = lambda a: a.ctypes.data_as(C.c_void_p)
+            rc = lib().yolo2_hip_load_weights_int16_bcast(self._h, vp(w), w.size, vp(b), b.size, vp(wq), wq.size, vp(bq), bq.size,
+                                                          vp(aq), aq.size, root)
+        else:
+            rc = lib().yolo2_hip_load_weights_int16_bcast(self._h, None, 0, None, 0, None, 0, None, 0, None, 0, root)
+        check(rc, "yolo2_hip_load_weights_int16_bcast")
+
+    def load_model_fp32_bcast(self, model, root: int = 0):
+        if model is not None:
+            w = np.ascontiguousarray(model.weights_f32(), dtype=np.float32)
+            b = np.ascontiguousarray(model.bias_f32(), dtype=np.float32)
+            rc = lib().yolo2_hip_load_weights_fp32_bcast(self._h, w.ctypes.data_as(C.c_void_p), w.size, b.ctypes.data_as(C.c_void_p),
+                                                         b.size, root)
+        else:
+            rc = lib().yolo2_hip_load_weights_fp32_bcast(self._h, None, 0, None, 0, root)
+        check(rc, "yolo2_hip_load_weights_fp32_bcast")
+
+
+for _name, _fn in list(vars(_BcastMixin).items()):
+    if not _name.startswith("__"):
+        setattr(Yolo2Hip, _name, _fn)
+
+
+class Yolo2HipMulti:
+    """One process, several devices (yolo2_hip_multi): contiguous frame shards, weights broadcast once."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        self._m = C.c_void_p(0)
+        check(lib().yolo2_hip_multi_create(devs, len(devices), C.byref(self._m)), "yolo2_hip_multi_create")
+        self.devices = list(devices)
+
+    def close(self):
+        if self._m:
+            lib().yolo2_hip_multi_destroy(self._m)
+            self._m = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def uses_rccl(self) -> bool:
+        return bool(lib().yolo2_hip_multi_uses_rccl(self._m))
+
+    def load_model(self, model):
+        w = np.ascontiguousarray(model.weights_i16(), dtype=np.int16)
+        b = np.ascontiguousarray(model.bias_i16(), dtype=np.int16)
+        wq, bq, aq = (np.ascontiguousarray(a, dtype=np.int32) for a in (model.weight_q, model.bias_q, model.act_q))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().yolo2_hip_multi_load_weights_int16(self._m, vp(w), w.size, vp(b), b.size, vp(wq), wq.size, vp(bq), bq.size,
+                                                       vp(aq), aq.size), "yolo2_hip_multi_load_weights_int16")
+
+    def run_frames(self, frames: np.ndarray, batch_per_device: int):
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        n = frames.shape[0]
+        region = np.empty((n, 425, 13, 13), dtype=np.int16)
+        q = C.c_int(0)
+        check(lib().yolo2_hip_multi_run_frames_int16(self._m, frames.ctypes.data_as(C.c_void_p), n, batch_per_device,
+                                                     region.ctypes.data_as(C.c_void_p), C.byref(q)), "yolo2_hip_multi_run_frames_int16")
+        return region, q.value
+
+    def run_images(self, images, batch_per_device: int):
+        imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+        n = len(imgs)
+        ch = 1 if imgs[0].ndim == 2 else imgs[0].shape[2]
+        ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+        ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+        hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+        region = np.empty((n, 425, 13, 13), dtype=np.int16)
+        q = C.c_int(0)
+        check(lib().yolo2_hip_multi_run_images_u8_host(self._m, ptrs, ws, hs, ch, n, batch_per_device, region.ctypes.data_as(C.c_void_p),
+                                                       C.byref(q)), "yolo2_hip_multi_run_images_u8_host")
+        return region, q.value
