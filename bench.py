@@ -198,10 +198,12 @@ def bench_fp16(args, world, rank, local_rank, dev):
     broadcast (the same one the int16 bench uses) puts it on every GPU."""
     B = args.batch
     model = synth.SynthModel(seed=1) if rank == 0 else None
-    wf, bf = ydist.broadcast_model_f32(model, dev)
     ctx = hipdrv.Yolo2Hip(local_rank)
-    ctx.load_weights_fp32(wf.cpu().numpy(), bf.cpu().numpy())
-    del wf, bf
+    if dist.is_initialized():   # the library's own RCCL broadcast (shared with the C host's --devices path)
+        ctx.rccl_init_rank(ydist.exchange_unique_id(hipdrv.rccl_unique_id, dev), world, rank)
+        ctx.load_model_fp32_bcast(model, root=0)
+    else:
+        ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
     lo, hi = ydist.shard_range(B * world, rank, world)
     frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
     region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
@@ -334,12 +336,17 @@ def main():
     B = args.batch
     if args.precision == "fp16":
         return bench_fp16(args, world, rank, local_rank, dev)
-    # ---- init: rank 0 builds the synthetic weight set; ONE broadcast puts it on every GPU
+    # ---- init: rank 0 builds the synthetic weight set; ONE broadcast puts it on every GPU.  The broadcast is the
+    # library's (yolo2_hip_load_weights_int16_bcast: ncclBroadcast from librccl.so over its own communicator, the same
+    # routine the C host's `yolov2_detect --devices` uses); torch.distributed only carries the 128-byte communicator id,
+    # the barrier and the max-over-ranks of the timing.
     model = synth.SynthModel(seed=1) if rank == 0 else None
-    w, b, wq, bq, aq = ydist.broadcast_model(model, dev)
     ctx = hipdrv.Yolo2Hip(local_rank)
-    ctx.load_weights_dev(w.data_ptr(), w.numel(), b.data_ptr(), b.numel(), wq, bq, aq)
-    del w, b
+    if dist.is_initialized():
+        ctx.rccl_init_rank(ydist.exchange_unique_id(hipdrv.rccl_unique_id, dev), world, rank)
+        ctx.load_model_bcast(model, root=0)
+    else:
+        ctx.load_model(model)
     ctx.set_batch(B)
 
     # ---- this rank's shard of the global synthetic batch, resident in HBM before timing

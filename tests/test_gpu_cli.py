@@ -99,3 +99,80 @@ def test_cli_rejects_other_backends_and_missing_files(tmp_path):
     assert r.returncode == 1 and "Unsupported backend" in r.stderr
     r = subprocess.run([CLI, "--cfg", "/nonexistent.cfg"], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "Fatal error" in r.stderr
+
+
+# ------------------------------------------------------------------ streaming frontend
+
+def _write_ppm(path, rgb):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]) + np.ascontiguousarray(rgb, dtype=np.uint8).tobytes())
+
+
+def _run(args, cwd):
+    r = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names")] + args,
+                       capture_output=True, text=True, cwd=str(cwd), env=dict(os.environ, YOLO2_NO_DUMP="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r
+
+
+def test_cli_streaming_list_dir_video_jsonl(tmp_path):
+    """N images of different sizes through --input-list / --input-dir (chunks of 3, two contexts on the one GPU, tail on
+    the GPU and on the host) and as a raw RGB24 stream: one JSONL record per frame with the reference's fields
+    (linux_app/src/main.c:1028-1077), one "Frame i (infer k) inference time: x ms" line per frame (the format
+    scripts/yolo2_report.py:685-729 parses), and every record's detections equal to the single-image run of that image."""
+    import json
+    import re
+    model = synth.SynthModel(seed=1, obj_bias=2.0)
+    wdir = tmp_path / "weights"
+    model.write_files(str(wdir), fp32=False)
+    rng = np.random.default_rng(8)
+    sizes = [(300, 500), (416, 416), (240, 320), (576, 768), (100, 60), (333, 333), (480, 640)]
+    idir = tmp_path / "imgs"
+    idir.mkdir()
+    paths = []
+    for k, (h, w) in enumerate(sizes):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        img[h // 4: h // 2, w // 4: w // 2] = rng.integers(0, 256, 3, dtype=np.uint8)     # a flat patch, for variety
+        p = idir / f"im_{k:02d}.ppm"
+        _write_ppm(p, img)
+        paths.append(str(p))
+    (tmp_path / "list.txt").write_text("# seven images\n" + "\n".join(paths) + "\n")
+    common = ["--weights", str(wdir), "--thresh", "0.1"]
+    # reference records: one single-image run per file (host letterbox, host tail)
+    single = []
+    for k, p in enumerate(paths):
+        _run(common + ["--input", p, "--output", str(tmp_path / "single" / f"p{k}"), "--jsonl", str(tmp_path / f"s{k}.jsonl")], tmp_path)
+        rec = json.loads((tmp_path / f"s{k}.jsonl").read_text())
+        assert rec["mode"] == "image" and rec["width"] == sizes[k][1] and rec["height"] == sizes[k][0]
+        single.append(rec)
+    assert sum(len(r["detections"]) for r in single) > 10
+    for tag, extra in (("gpu2", ["--input-list", str(tmp_path / "list.txt"), "--devices", "0,0", "--batch", "3", "--post", "gpu"]),
+                       ("host1", ["--input-dir", str(idir), "--batch", "4", "--post", "host"])):
+        out = tmp_path / f"{tag}.jsonl"
+        r = _run(common + extra + ["--jsonl", str(out), "--save-annotated-dir", str(tmp_path / f"ann_{tag}")], tmp_path)
+        recs = [json.loads(l) for l in out.read_text().splitlines()]
+        assert len(recs) == len(paths)
+        times = re.findall(r"Frame (\d+) \(infer (\d+)\) inference time: ([0-9.]+) ms", r.stdout)
+        assert [(int(a), int(b)) for a, b, _ in times] == [(k + 1, k + 1) for k in range(len(paths))]
+        for k, rec in enumerate(recs):
+            assert set(rec) == {"mode", "source", "frame_index", "inference_index", "width", "height", "detections"}
+            assert rec["source"] == paths[k] and rec["frame_index"] == k + 1 and rec["inference_index"] == k + 1
+            assert (rec["width"], rec["height"]) == (single[k]["width"], single[k]["height"])
+            assert rec["detections"] == single[k]["detections"], (tag, k)
+            for d in rec["detections"]:
+                assert set(d) == {"class_id", "label", "prob", "bbox_norm", "bbox_px"} and set(d["bbox_px"]) == {"x0", "y0", "x1", "y1"}
+        assert len(os.listdir(tmp_path / f"ann_{tag}")) == len(paths)
+        assert "Streaming inference completed successfully (7 inference frames" in r.stdout
+    # raw RGB24 stream: 5 frames of 320x240 = image 2 repeated with small changes; every 2nd frame, at most 2 inferences
+    h, w = sizes[2]
+    base = np.frombuffer(open(paths[2], "rb").read()[-h * w * 3:], dtype=np.uint8).reshape(h, w, 3)
+    with open(tmp_path / "video.rgb", "wb") as f:
+        for k in range(5):
+            f.write(np.roll(base, 7 * k, axis=1).tobytes())
+        f.write(b"\x00" * 100)        # a trailing partial frame is dropped
+    out = tmp_path / "video.jsonl"
+    r = _run(common + ["--video-raw", str(tmp_path / "video.rgb"), "--video-width", str(w), "--video-height", str(h), "--infer-every", "2",
+                       "--max-frames", "2", "--batch", "8", "--jsonl", str(out)], tmp_path)
+    recs = [json.loads(l) for l in out.read_text().splitlines()]
+    assert [(x["mode"], x["frame_index"], x["inference_index"]) for x in recs] == [("video", 1, 1), ("video", 3, 2)]
+    assert recs[0]["detections"] == single[2]["detections"]

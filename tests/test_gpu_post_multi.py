@@ -67,22 +67,20 @@ def test_gpu_postprocess_batch_equals_host_rows_in_order():
     (postprocess_batch, pinned to the reference on CPU): the whole dets[] array of every frame, element for element and
     in the same ORDER - the 80 successive stable sorts included - at a low threshold that keeps hundreds of candidates
     and many classes busy, ragged image sizes, with and without NMS."""
-    import torch
     model = synth.SynthModel(seed=1)
     B = 12
     frames = np.concatenate([synth.frames(7, 1), synth.frames(321, B - 1)])
     ctx = hipdrv.Yolo2Hip(0)
     ctx.load_model(model)
-    fd = torch.from_numpy(frames).cuda()
-    rd = torch.empty((B, 425, 13, 13), dtype=torch.int16, device="cuda")
-    q = ctx.run_batch_ptr(fd.data_ptr(), B, rd.data_ptr(), 0)
-    torch.cuda.synchronize()
-    region = rd.cpu().numpy()
+    fd = hipdrv.DevBuf(frames)                                   # (device memory through the library: no torch in this process)
+    rd = hipdrv.DevBuf(nbytes=B * 425 * 169 * 2)
+    q = ctx.run_batch_ptr(fd.addr, B, rd.addr, 0)
+    region = rd.get(np.int16, (B, 425, 13, 13))                 # (a blocking copy on the null stream: orders behind the pass)
     assert np.array_equal(region[0].reshape(-1), FULL["i16/std/region_raw_i16"])
     ws = [768, 416, 500, 640, 1, 1920, 333, 416, 100, 4000, 640, 77]
     hs = [576, 416, 375, 480, 1, 1080, 999, 415, 100, 3000, 360, 78]
     for thresh, nms in ((0.004, 0.45), (0.02, 0.3), (0.24, 0.45), (0.02, 0.0)):
-        out = hipdrv.postprocess(ctx, rd.data_ptr(), B, ws, hs, thresh, nms, final_q=q, cap=4096, want_rows=True)
+        out = hipdrv.postprocess(ctx, rd.addr, B, ws, hs, thresh, nms, final_q=q, cap=4096, want_rows=True)
         rows, totals = _host_rows(region, q, ws, hs, thresh, nms)
         if nms <= 0:      # (without NMS the host keeps all 845 slots; the candidates in front are what counts)
             totals = out["totals"]
@@ -100,29 +98,28 @@ def test_gpu_postprocess_dog_and_throughput():
     (tests/golden/dog.npz); and the rate on a batch-256 tensor resident in HBM (the fp16 path produces ~28 k frames/s:
     the tail must not be the bottleneck)."""
     import time
-    import torch
     q = int(DOG["i16/final_q"])
     W, H, thresh, nms = DOG["i16/detect_params"]
     ctx = hipdrv.Yolo2Hip(0)
-    one = torch.from_numpy(DOG["i16/region_raw_i16"].reshape(1, -1).copy()).cuda()
-    out = hipdrv.postprocess(ctx, one.data_ptr(), 1, [int(W)], [int(H)], float(thresh), float(nms), final_q=q, cap=4096, want_rows=True)
+    one = hipdrv.DevBuf(DOG["i16/region_raw_i16"].reshape(1, -1).copy())
+    out = hipdrv.postprocess(ctx, one.addr, 1, [int(W)], [int(H)], float(thresh), float(nms), final_q=q, cap=4096, want_rows=True)
     assert np.array_equal(orclib.canon_rows(out["rows"][0]).view(np.uint32), DOG["i16/detect_rows"].view(np.uint32))
     B = 256
     rng = np.random.default_rng(0)
     base = DOG["i16/region_raw_i16"].astype(np.int32)
     batch = np.stack([np.clip(np.roll(base, 173 * f) + rng.integers(-2, 3, base.size), -32768, 32767) for f in range(B)]).astype(np.int16)
-    rd = torch.from_numpy(batch).cuda()
+    rd = hipdrv.DevBuf(batch)
     ws, hs = [768] * B, [576] * B
-    hipdrv.postprocess(ctx, rd.data_ptr(), B, ws, hs, 0.24, 0.45, final_q=q, cap=128)
+    hipdrv.postprocess(ctx, rd.addr, B, ws, hs, 0.24, 0.45, final_q=q, cap=128)
     t0 = time.perf_counter()
     reps = 5
     for _ in range(reps):
-        res = hipdrv.postprocess(ctx, rd.data_ptr(), B, ws, hs, 0.24, 0.45, final_q=q, cap=128)
+        res = hipdrv.postprocess(ctx, rd.addr, B, ws, hs, 0.24, 0.45, final_q=q, cap=128)
     dt = (time.perf_counter() - t0) / reps
     fps = B / dt
     print(f"GPU region+boxes+NMS: {fps:.0f} frames/s at batch {B} (thresh 0.24)")
     rows, totals = _host_rows(batch[:8], q, ws[:8], hs[:8], 0.24, 0.45)
-    full = hipdrv.postprocess(ctx, rd.data_ptr(), 8, ws[:8], hs[:8], 0.24, 0.45, final_q=q, cap=128, want_rows=True)
+    full = hipdrv.postprocess(ctx, rd.addr, 8, ws[:8], hs[:8], 0.24, 0.45, final_q=q, cap=128, want_rows=True)
     for f in range(8):
         assert np.array_equal(full["rows"][f, :totals[f]].view(np.uint32), rows[f, :totals[f]].view(np.uint32))
     assert fps >= 30000, fps

@@ -84,8 +84,10 @@ def test_layer_table_totals():
 
 def test_shard_range_covers_everything():
     from yolo2_amd import dist as ydist
-    for total, world in [(2048, 8), (10, 4), (3, 8), (64, 1)]:
+    for total, world in [(2048, 8), (10, 4), (3, 8), (64, 1), (0, 3), (2047, 8), (13, 3)]:
         got = [ydist.shard_range(total, r, world) for r in range(world)]
+        # the C host's arithmetic (yolo2_hip_shard_range, used by yolo2_hip_multi_run_*) is the same
+        assert got == [hipdrv.shard_range(total, r, world) for r in range(world)]
         assert got[0][0] == 0 and got[-1][1] == total
         assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
         assert max(h - l for l, h in got) - min(h - l for l, h in got) <= 1
@@ -100,6 +102,9 @@ def _gloo_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model = s.SynthModel(seed=4) if rank == 0 else None
     w, b, wq, bq, aq = ydist.broadcast_model(model, torch.device("cpu"))
+    # the launcher's part of the library's rank API: rank 0's 128-byte communicator id reaches every rank
+    uid = ydist.exchange_unique_id(lambda: bytes(range(100, 228)), torch.device("cpu"))
+    assert uid == bytes(range(100, 228)), "communicator id did not arrive"
     lo, hi = ydist.shard_range(10, rank, world)
     frames = s.frames(11, hi - lo, first=lo)
     # every rank reports a checksum of what it received and of its frame shard
@@ -129,3 +134,17 @@ def test_weight_broadcast_and_frame_sharding_world2_gloo():
     assert (res[0][4], res[0][5], res[1][4], res[1][5]) == (0, 5, 5, 10)
     whole = synth.frames(11, 10).astype(np.float64)
     assert abs(res[0][6] - whole[:5].sum()) < 1e-6 and abs(res[1][6] - whole[5:].sum()) < 1e-6
+
+
+def test_shard_range_rejects_bad_arguments_and_multi_needs_a_gpu():
+    L = hipdrv.lib()
+    lo, hi = ctypes.c_int(0), ctypes.c_int(0)
+    assert L.yolo2_hip_shard_range(10, 3, 3, ctypes.byref(lo), ctypes.byref(hi)) == hipdrv.YOLO2_ERROR
+    assert L.yolo2_hip_shard_range(10, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) == hipdrv.YOLO2_ERROR
+    if L.yolo2_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    devs = (ctypes.c_int * 2)(0, 1)
+    m = ctypes.c_void_p(0)
+    assert L.yolo2_hip_multi_create(devs, 2, ctypes.byref(m)) == hipdrv.YOLO2_INIT_ERROR     # loud, no CPU fallback
+    assert b"no HIP device" in L.yolo2_hip_last_error()
+    assert L.dma_buffer_init() == -1

@@ -184,7 +184,7 @@ int pnm_int(FILE *f)
 }
 }  // namespace
 
-Image load_pnm(const std::string &path)
+ImageU8 load_pnm_u8(const std::string &path)
 {
     FILE *f = fopen(path.c_str(), "rb");
     if (!f) throw std::runtime_error("Cannot load image \"" + path + "\"");
@@ -203,12 +203,24 @@ Image load_pnm(const std::string &path)
     const size_t rd = fread(raw.data(), 1, raw.size(), f);
     fclose(f);
     if (rd != raw.size()) throw std::runtime_error("Short read: " + path);
+    ImageU8 im;
+    im.w = w; im.h = h;
+    if (chans == 3) im.rgb = std::move(raw);
+    else {
+        im.rgb.resize((size_t)w * h * 3);
+        for (size_t i = 0; i < (size_t)w * h; ++i) im.rgb[3 * i] = im.rgb[3 * i + 1] = im.rgb[3 * i + 2] = raw[i];
+    }
+    return im;
+}
+
+Image load_pnm(const std::string &path)
+{
+    const ImageU8 u = load_pnm_u8(path);
     // like load_image_stb (src/core/yolo_image.cpp): always 3 planes, HWC bytes -> CHW floats /255
-    Image im = make_image(w, h, 3);
+    Image im = make_image(u.w, u.h, 3);
     for (int k = 0; k < 3; ++k)
-        for (int y = 0; y < h; ++y)
-            for (int x = 0; x < w; ++x)
-                im.at(x, y, k) = (float)raw[((size_t)y * w + x) * chans + (chans == 3 ? k : 0)] / 255.f;
+        for (int y = 0; y < u.h; ++y)
+            for (int x = 0; x < u.w; ++x) im.at(x, y, k) = (float)u.rgb[((size_t)y * u.w + x) * 3 + k] / 255.f;
     return im;
 }
 

@@ -38,6 +38,12 @@ struct Image {
 };
 Image make_image(int w, int h, int c);
 Image load_pnm(const std::string &path);                 // binary P6 (RGB) / P5 (grey), 8-bit
+// the same file as interleaved bytes (what stbi_load hands load_image_stb before its /255.): RGB, grey replicated
+struct ImageU8 {
+    int w = 0, h = 0;
+    std::vector<uint8_t> rgb;   // [h][w][3]
+};
+ImageU8 load_pnm_u8(const std::string &path);
 void save_ppm(const Image &im, const std::string &path);
 Image resize_image(const Image &im, int w, int h);        // yolo_image.cpp:84-126 (two-pass bilinear)
 Image letterbox_image(const Image &im, int w, int h);     // yolo_image.cpp:148-165 (grey 0.5 bars)

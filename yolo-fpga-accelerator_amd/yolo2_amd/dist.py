@@ -9,10 +9,24 @@ from . import net
 
 
 def shard_range(total: int, rank: int, world: int):
-    """Contiguous frame range [lo, hi) of `rank`; sizes differ by at most one."""
+    """Contiguous frame range [lo, hi) of `rank`; sizes differ by at most one.  (Same arithmetic as the library's
+    yolo2_hip_shard_range, which the C host uses; tests/test_host_logic.py holds the two against each other.)"""
     base, rem = divmod(total, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def exchange_unique_id(make_id, device: torch.device, src: int = 0) -> bytes:
+    """The launcher's part of the library's one-process-per-GPU model (include/yolo2_hip.h, multi-GPU (b)): rank `src`
+    makes the 128-byte RCCL id (make_id = hipdrv.rccl_unique_id -> ncclGetUniqueId), the job's process group carries it
+    to every rank.  After that the weight broadcast itself is the LIBRARY's ncclBroadcast, not torch's."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    t = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == src:
+        t.copy_(torch.frombuffer(bytearray(make_id()), dtype=torch.uint8))
+    if dist.is_initialized():
+        dist.broadcast(t, src)
+    return bytes(t.cpu().numpy().tobytes())
 
 
 def pack_q_tables(weight_q, bias_q, act_q) -> torch.Tensor:
