@@ -279,6 +279,41 @@ def sub_fp16_b256(model, dev, steps=5, warmup=2):
     return rec
 
 
+FP32_VALU_CYCLES_PER_STEP = 18     # 4 v_mul_f32 + 5 v_add_f32 (partial sum from +0, then the accumulator) at 2 issue cycles each
+
+
+def sub_fp32_exact(model, dev, B=32, steps=3, warmup=1):
+    """The exact fp32 form (configs[0]'s precision) on the tiled kernel: bit-identical to the reference's fp32 region tensor;
+    VALU-issue bound like the int16 path (no FMA allowed: every product and sum is rounded like the reference's)."""
+    ctx = hipdrv.Yolo2Hip(dev.index or 0)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    base = synth.frames(7, 4)
+    frames = torch.from_numpy(base).to(dev).repeat(B // 4, 1, 1, 1).contiguous()
+    region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(warmup):
+        ctx.run_batch_fp32_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_batch_fp32_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    dt = (time.perf_counter() - t0) / steps
+    import orclib
+    orclib.oracle().orc_set_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = orclib.forward_f32(model, base[1])
+    exact = bool(np.array_equal(region[1].cpu().numpy().reshape(-1).view(np.uint32), ref.view(np.uint32)) and torch.equal(region[1], region[B - 3]))
+    need = net.requant_steps_per_frame() * B / 64 * FP32_VALU_CYCLES_PER_STEP
+    ctx.close()
+    return {"metric": "YOLOv2 fp32 (reference arithmetic) 416x416 frames/sec", "value": B / dt, "unit": "frames/s", "ms_per_step": dt * 1e3,
+            "steps": steps, "warmup": warmup, "dtype": "f32",
+            "config": {"workload": f"YOLOv2 fp32 416x416 batch={B}, tiled conv in the reference's operation order (no FMA)"},
+            "bit_exact_vs_fp32_oracle": exact,
+            "valu_roofline": {"bound": "valu_issue", "achieved": need / dt / 1e12, "peak": VALU_PEAK_TCYCLES, "unit": "T SIMD issue cycles/s",
+                              "frac": need / dt / 1e12 / VALU_PEAK_TCYCLES,
+                              "note": "18 issue cycles per (4 channels x tap x 64 outputs): 4 v_mul_f32 + 5 v_add_f32 at 2 cycles each"}}
+
+
 def sub_latency_b1(ctx, frames, region, dev, n=30):
     """configs[1] under the driver's clock: one frame per call, one host sync per frame (device-resident in and out)."""
     stream = torch.cuda.current_stream(dev)
@@ -460,6 +495,7 @@ def main():
             result["latency_b1"]["matches_batched_result_bit_exact"] = bool(torch.equal(region[0], r0))
             ctx.close()
             result["fp16_b256"] = sub_fp16_b256(model, dev)
+            result["fp32_exact_b32"] = sub_fp32_exact(model, dev)
         print(json.dumps(result), flush=True)
     if dist.is_initialized():
         dist.barrier()

@@ -264,6 +264,14 @@ int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x
  * yolo2_hip_run_batch_fp16.  Needs yolo2_hip_load_weights_fp32. */
 int yolo2_hip_run_frame_fp32_host(yolo2_hip_ctx *ctx, const float *frame, float *region);
 
+/* The same exact fp32 arithmetic, batched and TILED (csrc/kernels_f32.hpp: LDS-staged input tiles, scalar weight
+ * loads, P pixels x 8 channels of fp32 accumulators per lane, the reference's operation order kept product by product):
+ * bit-identical to the reference's fp32 region tensor at a few hundred times the one-thread-per-output pass.
+ *   frames_dev  float [batch][3][416][416]      region_dev  float [batch][425][13][13]      (device)
+ * Asynchronous on `stream` like the other batched entries; the _host form is synchronous. */
+int yolo2_hip_run_batch_fp32(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch, uint64_t region_dev, void *stream);
+int yolo2_hip_run_batch_fp32_host(yolo2_hip_ctx *ctx, const float *frames, int batch, float *region);
+
 /* GPU pre-processing (the step before the path): the reference host's
  * load_image_stb (bytes / 255.f, src/core/yolo_image.cpp:29-63) + letterbox_image (two-pass bilinear
  * resize_image onto a 0.5 canvas, src/core/yolo_image.cpp:84-165) as one kernel, float-for-float in

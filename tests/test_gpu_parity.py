@@ -883,3 +883,34 @@ def test_conv_pool_fusion_default_and_disabled(monkeypatch):
     assert np.array_equal(r1, r2)
     ctx.debug_layer_output(6, 3)
     ctx.close()
+
+
+@pytest.mark.parametrize("P", [None, "1", "2", "4"])
+def test_fp32_tiled_batch_bit_exact(P, monkeypatch):
+    """yolo2_hip_run_batch_fp32: the reference's fp32 arithmetic (core_compute.cpp:121-172: products and sums rounded one
+    by one, no FMA) on the tiled kernel, every pixels-per-lane instantiation.  Frame 0 = the compiled reference's fp32
+    region tensor bit for bit (fixture), frame 3 = dog.jpg's (fixture), the rest against the one-thread-per-output pass
+    and the oracle; tiles straddle frames (5 frames)."""
+    if P is not None:
+        monkeypatch.setenv("YOLO2_F32_P", P)
+    import hashlib
+    model = synth.SynthModel(seed=1)
+    rgb = DOG["rgb"]
+    dog = hipdrv.letterbox_u8(rgb)
+    assert hashlib.sha256(dog.tobytes()).digest() == DOG["frame_sha256"].tobytes()
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(99, 2), dog[None], synth.frames(7, 1)])
+    ctx = hipdrv.Yolo2Hip(0)
+    with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):
+        ctx.run_batch_fp32_host(frames[:1])
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    got = ctx.run_batch_fp32_host(frames)
+    u = lambda a: np.ascontiguousarray(a).reshape(-1).view(np.uint32)
+    assert np.array_equal(u(got[0]), u(FULL["f32/std/region_raw_f32"]))
+    assert np.array_equal(u(got[4]), u(got[0]))
+    assert np.array_equal(u(got[3]), u(DOG["f32/region_raw_f32"]))
+    assert np.array_equal(u(got[1]), u(ctx.run_frame_fp32_host(frames[1])))
+    orclib.oracle().orc_set_threads(16)
+    assert np.array_equal(u(got[2]), u(orclib.forward_f32(model, frames[2])))
+    one = ctx.run_batch_fp32_host(frames[2:3])
+    assert np.array_equal(u(one[0]), u(got[2]))
+    ctx.close()

@@ -74,7 +74,7 @@ void print_usage(const char *prog)
         "  --nms <float>         NMS IoU threshold (default: 0.45)\n"
         "  --hier <float>        Hierarchical threshold (accepted, unused by region layers)\n"
         "  --backend <hip>       Backend selector (hip = MI355X library; hls/cpu live in the reference build)\n"
-        "  --precision <int16|fp32>  int16 = the batched fixed-point path; fp32 = the exact fp32 pass (one frame)\n"
+        "  --precision <int16|fp32>  int16 = the batched fixed-point path; fp32 = the exact fp32 pass (tiled, batched)\n"
         "  --batch <n>           Frames per accelerator call (default 1)\n"
         "  --device <n>          HIP device (default 0)\n"
         "  --devices <a,b,..>    Several HIP devices: frames shard contiguously, weights are broadcast once (RCCL)\n"
@@ -491,10 +491,13 @@ void run_detector(AppConfig cfg)
         const std::vector<float> w = read_floats(cfg.weights_dir + "/weights_reorg.bin", (size_t)YOLO2_N_WEIGHTS);
         const std::vector<float> b = read_floats(cfg.weights_dir + "/bias.bin", (size_t)YOLO2_N_BIAS);
         if (yolo2_hip_load_weights_fp32(ctx, w.data(), w.size(), b.data(), b.size()) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+        // the tiled exact fp32 pass (bit-identical to the reference's fp32 path); --batch N repeats the frame like the int16 branch
+        std::vector<float> frames((size_t)cfg.batch * YOLO2_FRAME_ELEMS), regions((size_t)cfg.batch * YOLO2_REGION_ELEMS);
+        for (int b = 0; b < cfg.batch; ++b) std::memcpy(frames.data() + (size_t)b * YOLO2_FRAME_ELEMS, sized.data.data(), sizeof(float) * YOLO2_FRAME_ELEMS);
         const auto t0 = std::chrono::high_resolution_clock::now();
-        if (yolo2_hip_run_frame_fp32_host(ctx, sized.data.data(), raw.data()) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+        if (yolo2_hip_run_batch_fp32_host(ctx, frames.data(), cfg.batch, regions.data()) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
         elapsed = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
-        frames_run = 1;
+        std::memcpy(raw.data(), regions.data(), sizeof(float) * YOLO2_REGION_ELEMS);
     } else {
         std::vector<int> wlen(yolo2_weight_len, yolo2_weight_len + YOLO2_N_CONV), blen(yolo2_bias_len, yolo2_bias_len + YOLO2_N_CONV);
         const y2h::WeightsI16 wp = y2h::load_weights_int16(cfg.weights_dir, wlen, blen);

@@ -35,7 +35,7 @@ EXPORTS = [
     "yolo2_hip_layer_pool_fused", "yolo2_get_status", "yolo2_read_reg", "yolo2_write_reg", "yolo2_hip_driver_calls",
     "dma_buffer_init", "dma_buffer_cleanup", "dma_buffer_alloc", "dma_buffer_free", "dma_buffer_sync_for_device",
     "dma_buffer_sync_for_cpu", "dma_buffer_get_phys",
-    "yolo2_hip_load_weights_fp32_dev", "yolo2_hip_postprocess_int16", "yolo2_hip_postprocess_f32",
+    "yolo2_hip_run_batch_fp32", "yolo2_hip_run_batch_fp32_host", "yolo2_hip_load_weights_fp32_dev", "yolo2_hip_postprocess_int16", "yolo2_hip_postprocess_f32",
     "yolo2_hip_shard_range", "yolo2_hip_multi_create", "yolo2_hip_multi_destroy", "yolo2_hip_multi_num_devices",
     "yolo2_hip_multi_uses_rccl", "yolo2_hip_multi_ctx", "yolo2_hip_multi_load_weights_int16", "yolo2_hip_multi_load_weights_fp32",
     "yolo2_hip_multi_run_frames_int16", "yolo2_hip_multi_run_images_u8_host", "yolo2_hip_rccl_unique_id",
@@ -118,6 +118,8 @@ def lib():
     L.yolo2_hip_run_batch_fp16.argtypes = [vp, u64, i32, u64, vp]
     L.yolo2_hip_run_batch_fp16_host.argtypes = [vp, vp, i32, vp]
     L.yolo2_hip_run_frame_fp32_host.argtypes = [vp, vp, vp]
+    L.yolo2_hip_run_batch_fp32.argtypes = [vp, u64, i32, u64, vp]
+    L.yolo2_hip_run_batch_fp32_host.argtypes = [vp, vp, i32, vp]
     L.yolo2_hip_letterbox_u8.argtypes = [u64, i32, i32, i32, u64, i32, i32, vp]
     L.yolo2_hip_run_images_u8_host.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp, C.POINTER(i32)]
     L.memory_get_phys_addr.restype = u64
@@ -351,6 +353,18 @@ class Yolo2Hip:
         region = np.empty((425, 13, 13), dtype=np.float32)
         check(lib().yolo2_hip_run_frame_fp32_host(self._h, f.ctypes.data_as(C.c_void_p), region.ctypes.data_as(C.c_void_p)),
               "yolo2_hip_run_frame_fp32_host")
+        return region
+
+    def run_batch_fp32_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0):
+        check(lib().yolo2_hip_run_batch_fp32(self._h, frames_ptr, batch, region_ptr, C.c_void_p(stream)), "yolo2_hip_run_batch_fp32")
+
+    def run_batch_fp32_host(self, frames: np.ndarray) -> np.ndarray:
+        """The tiled exact fp32 pass (bit-identical to the reference's fp32 path) on a batch of host frames."""
+        frames = np.ascontiguousarray(frames, dtype=np.float32)
+        B = frames.shape[0]
+        region = np.empty((B, 425, 13, 13), dtype=np.float32)
+        check(lib().yolo2_hip_run_batch_fp32_host(self._h, frames.ctypes.data_as(C.c_void_p), B, region.ctypes.data_as(C.c_void_p)),
+              "yolo2_hip_run_batch_fp32_host")
         return region
 
     def run_batch_fp16_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0):
