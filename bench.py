@@ -149,6 +149,7 @@ def hbm_traffic_per_launch(ks, batch):
         return None, f"{TRAFFIC_FILE} holds no entry for KS={ks}"
 
 
+print_record = None                # set by main(): writes the one JSON line to the original stdout
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 
 
@@ -243,7 +244,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
             result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
                                       "sample": "1 frame through oracle/yolo2_oracle.c fp32 (bit-exact restatement of the reference's fp32 path), single thread",
                                       "seconds_per_frame": cdt, "gpu_max_abs_err_vs_cpu": err}
-        print(json.dumps(result), flush=True)
+        print_record(result)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -338,6 +339,18 @@ def sub_latency_b1(ctx, frames, region, dev, n=30):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON record.  Libraries chat on fd 1 (RCCL prints a version banner there when a
+    # communicator is created under NCCL_DEBUG=VERSION/WARN), so everything written to fd 1 during the run is sent to stderr
+    # and the record goes out through a private duplicate of the original stdout at the very end.
+    sys.stdout.flush()
+    out_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(out_fd, (json.dumps(record) + "\n").encode())
+
+    global print_record
+    print_record = emit
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -496,7 +509,7 @@ def main():
             ctx.close()
             result["fp16_b256"] = sub_fp16_b256(model, dev)
             result["fp32_exact_b32"] = sub_fp32_exact(model, dev)
-        print(json.dumps(result), flush=True)
+        print_record(result)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

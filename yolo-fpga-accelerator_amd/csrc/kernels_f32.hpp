@@ -10,12 +10,13 @@
 // reproduces the bits.  The one-thread-per-output kernel (k_conv_ref_f32) does that at ~5 frames/s; this file keeps
 // the order and borrows the int16 kernel's structure instead - items of 4 channels (here 4 floats = 16 bytes) in the
 // flat shared-zero-row/column layout of layout.hpp, the input tile of a channel group staged once per workgroup in LDS
-// (double-buffered, conflict-free ds_read_b128 by consecutive lanes), weights wave-uniform through scalar loads, P
-// pixels x 8 output channels of fp32 accumulators per lane.  Out-of-image taps and the 4th lane of the 3-channel input
+// (double-buffered, conflict-free ds_read_b128 by consecutive lanes), the group's weight slice staged beside it and read
+// back as broadcasts, P pixels x 8 output channels of fp32 accumulators per lane.  Out-of-image taps and the 4th lane of the 3-channel input
 // read stored zeros and are multiplied and added like the reference's zero-padded buffers are (w * 0 = +-0, ps + 0:
 // the same signed-zero behaviour, checked bit for bit against the compiled reference's fixture).
-// Issue cost: 4 v_mul_f32 + 4 v_add_f32 per (4 channels x tap x output) = 16 SIMD cycles per step and wavefront at
-// 2 cycles each -> 2.65 k frames/s is the VALU ceiling of the exact fp32 form (the fp16 MFMA path is the fast one).
+// Issue cost: 4 v_mul_f32 + 5 v_add_f32 per (4 channels x tap x output) = 18 SIMD cycles per step and wavefront at
+// 2 cycles each (all operands in VGPRs) -> 2.36 k frames/s is the VALU ceiling of the exact fp32 form (the fp16 MFMA
+// path is the fast one).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -42,8 +43,12 @@ template <int KS, int P, int NST>
 __global__ __launch_bounds__(256) void k_conv_f32(const float4 *__restrict__ in, float4 *__restrict__ out,
                                                    const float4 *__restrict__ wpk, const float *__restrict__ bias, const ConvArgs a)
 {
+    // Weights go through LDS too (staged with the input tile, read back with BROADCAST ds_read_b128: every lane of a
+    // wavefront reads the same 16 bytes), not through scalar loads as in the int16 kernel: on gfx950 any VALU instruction
+    // with an SGPR operand issues in 4 cycles instead of 2 (profiles/r02_ubench_valu_sgpr_operand.txt: v_mul_f32 2.09 vs
+    // 4.03), which would make the four multiplies of a step cost as much as its five adds together.
     extern __shared__ float4 ldsf[];
-    constexpr int T = 64 * P, KT = KS * KS;
+    constexpr int T = 64 * P, KT = KS * KS, WIT = KT * 32, NW = (WIT + 255) / 256;   // weight items (float4) per channel group
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x, mb = blockIdx.y;
@@ -54,6 +59,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float4 *__restrict__ in,
     const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
     const int tile_start = fmin - halo;
     const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
+    const int buf_items = a.lt_max + WIT;          // one LDS buffer: input tile, then the group's 32-channel weight slice
 
     int fo[P], rowaddr[P][KS];
     bool valid[P];
@@ -78,51 +84,68 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float4 *__restrict__ in,
     }
     const char *lds_b = reinterpret_cast<const char *>(ldsf);
     const float4 *src = in + kLead + tile_start;
-    const float4 *wq = wpk + ((long)mb * a.CGin * KT * 32 + wave * 8);
+    const float4 *wsrc = wpk + (long)mb * a.CGin * WIT;    // this block's 32 channels, group 0: [tap][32] items
+    int wrd = (a.lt_max + wave * 8) * 16;                   // byte offset of this wavefront's 8 channels, tap 0, inside a buffer
 
-    float4 stage[NST];
+    float4 stage[NST], wst[NW];
+    auto issue = [&]() {
 #pragma unroll
-    for (int k = 0; k < NST; ++k) {
-        const int i = tid + k * 256;
-        if (i < Lt) stage[k] = src[i];
-    }
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 256;
+            if (i < Lt) stage[k] = src[i];
+        }
 #pragma unroll
-    for (int k = 0; k < NST; ++k) {
-        const int i = tid + k * 256;
-        if (i < Lt) ldsf[i] = stage[k];
-    }
+        for (int k = 0; k < NW; ++k) {
+            const int i = tid + k * 256;
+            if (i < WIT) wst[k] = wsrc[i];
+        }
+    };
+    auto commit = [&](int b) {
+        float4 *dst = ldsf + b * buf_items;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 256;
+            if (i < Lt) dst[i] = stage[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = tid + k * 256;
+            if (i < WIT) dst[a.lt_max + i] = wst[k];
+        }
+    };
+    issue();
+    commit(0);
     __syncthreads();
     for (int cg = 0; cg < a.CGin; ++cg) {
         const bool more = cg + 1 < a.CGin;
         if (more) {
             src += a.in_cg_stride;
-#pragma unroll
-            for (int k = 0; k < NST; ++k) {
-                const int i = tid + k * 256;
-                if (i < Lt) stage[k] = src[i];
-            }
+            wsrc += WIT;
+            issue();
         }
-        const char *tl = lds_b + (cg & 1) * a.lt_max * 16;
+        const char *tl = lds_b + (cg & 1) * buf_items * 16;
 #pragma unroll
         for (int tap = 0; tap < KT; ++tap) {
             float4 w[8];
 #pragma unroll
-            for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];     // wave-uniform: scalar loads
+            for (int m = 0; m < 8; ++m) w[m] = *reinterpret_cast<const float4 *>(tl + wrd + (tap * 32 + m) * 16);   // broadcast reads
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 const float4 x = *reinterpret_cast<const float4 *>(tl + rowaddr[p][tap / KS] + (tap % KS) * 16);
                 step_f32(acc[p], x, w);
             }
-        }
-        if (more) {
-            float4 *nxt = ldsf + ((cg + 1) & 1) * a.lt_max;
+            // Without a tie between taps hipcc hoists the weight reads of all nine taps (288 VGPRs) to the top of the
+            // group.  Empty volatile asm statements keep their order: one per accumulator (all of this tap's sums exist
+            // here; with fewer, hipcc runs one channel through all taps first) and one on the weight offset the next
+            // tap reads from.  No instruction is emitted.
 #pragma unroll
-            for (int k = 0; k < NST; ++k) {
-                const int i = tid + k * 256;
-                if (i < Lt) nxt[i] = stage[k];
-            }
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) asm volatile("" : "+v"(acc[p][m]));
+            asm volatile("" : "+s"(wrd));
+            __builtin_amdgcn_sched_barrier(0);
         }
-        wq += KT * 32;
+        if (more) commit((cg + 1) & 1);
         __syncthreads();
     }
 #pragma unroll

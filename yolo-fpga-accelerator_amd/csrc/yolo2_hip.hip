@@ -2226,7 +2226,7 @@ static void plan_conv_f32(ConvPlan &p, const LayerDesc &l, const ActGeom &gin, l
     a.leaky = l.leaky;
     a.lt_max = tile_items_bound(gin, 64 * P, halo);
     a.mb_list = nullptr;
-    p.lds_bytes = a.lt_max * 16 * 2;
+    p.lds_bytes = (a.lt_max + l.size * l.size * 32) * 16 * 2;   // two buffers of {input tile, the group's 32-channel weight slice}
     p.grid = dim3((a.npix + 64 * P - 1) / (64 * P), (l.n + 31) / 32, 1);
     // same XCD grid rule as the int16 kernel (items and weights are twice as large: same ratio)
     const double in_bytes = (double)gin.B * gin.CG * gin.PL * 16, w_mb = (double)gin.CG * l.size * l.size * 32 * 16;

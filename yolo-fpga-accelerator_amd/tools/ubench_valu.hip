@@ -97,6 +97,10 @@ KERNEL(k_align, I_ALIGN)
 #define I_X_bfi(n) "v_bfi_b32 %" #n ", %8, %9, %" #n "\n\t"
 #define I_X_mini(n) "v_min_i32 %" #n ", %8, %" #n "\n\t"
 #define I_X_addsg(n) "v_add_u32 %" #n ", %10, %" #n "\n\t"
+#define I_X_mulfsg(n) "v_mul_f32 %" #n ", %10, %" #n "\n\t"
+#define I_X_addfsg(n) "v_add_f32 %" #n ", %10, %" #n "\n\t"
+#define I_X_movsg(n) "v_mov_b32 %" #n ", %10\n\t"
+#define I_X_fmacsg(n) "v_fmac_f32 %" #n ", %10, %8\n\t"
 #define I_X_subrev(n) "v_subrev_u32 %" #n ", %8, %" #n "\n\t"
 #define I_X_fmac(n) "v_fmac_f32 %" #n ", %8, %9\n\t"
 #define I_X_addi16(n) "v_add_i16 %" #n ", %" #n ", %8 clamp\n\t"
@@ -132,6 +136,10 @@ KERNEL(k_x_madu24, I_X_madu24)
 KERNEL(k_x_bfi, I_X_bfi)
 KERNEL(k_x_mini, I_X_mini)
 KERNEL(k_x_addsg, I_X_addsg)
+KERNEL(k_x_mulfsg, I_X_mulfsg)
+KERNEL(k_x_addfsg, I_X_addfsg)
+KERNEL(k_x_movsg, I_X_movsg)
+KERNEL(k_x_fmacsg, I_X_fmacsg)
 KERNEL(k_x_subrev, I_X_subrev)
 KERNEL(k_x_fmac, I_X_fmac)
 KERNEL(k_x_addi16, I_X_addi16)
@@ -159,7 +167,7 @@ int main()
         {"v_mad_i32_i16", k_madi16}, {"v_pk_mad_i16", k_pkmad}, {"v_dot4_i32_i8", k_dot4}, {"v_fma_f32", k_fma},
         {"v_perm_b32", k_perm}, {"v_lshl_add_u32", k_lshladd}, {"v_max_i32", k_max}, {"v_pk_max_i16", k_pkmax},
         {"v_bfe_i32", k_bfe}, {"v_alignbit_b32", k_align},
-        {"v_and_b32 [and]", k_x_and}, {"v_or_b32 [or]", k_x_or}, {"v_xor_b32 [xor]", k_x_xor}, {"v_lshlrev_b32 [lshl]", k_x_lshl}, {"v_sub_u32 [sub]", k_x_sub}, {"v_mov_b32 [mov]", k_x_mov}, {"v_cndmask_b32 [cndmask]", k_x_cndmask}, {"v_mul_lo_u32 [mullo]", k_x_mullo}, {"v_add3_u32 [add3]", k_x_add3}, {"v_max_f32 [maxf]", k_x_maxf}, {"v_min_f32 [minf]", k_x_minf}, {"v_med3_f32 [med3f]", k_x_med3f}, {"v_mul_f32 [mulf]", k_x_mulf}, {"v_add_f32 [addf]", k_x_addf}, {"v_cvt_f32_i32 [cvtfi]", k_x_cvtfi}, {"v_cvt_i32_f32 [cvtif]", k_x_cvtif}, {"v_mul_i32_i24 [mul24]", k_x_mul24}, {"v_mad_u32_u24 [madu24]", k_x_madu24}, {"v_bfi_b32 [bfi]", k_x_bfi}, {"v_min_i32 [mini]", k_x_mini}, {"v_add_u32 [addsg]", k_x_addsg}, {"v_subrev_u32 [subrev]", k_x_subrev}, {"v_fmac_f32 [fmac]", k_x_fmac}, {"v_add_i16 [addi16]", k_x_addi16}, {"v_max3_i32 [max3i]", k_x_max3i}, {"v_xad_u32 [xad]", k_x_xad}, {"v_lshl_or_b32 [lshlor]", k_x_lshlor}, {"v_add_lshl_u32 [addlshl]", k_x_addlshl}, {"v_and_or_b32 [andor_v]", k_x_andor_v}, {"v_dot2c_f32_f16 [dot2f]", k_x_dot2f}, {"v_sub_i32 [sat_sub]", k_x_sat_sub}, {"v_min_u32 [minu]", k_x_minu}, {"v_pk_min_u16 [pkminu]", k_x_pkminu}, {"v_mad_u16 [mad_u16]", k_x_mad_u16}, {"v_msad_u8 [msad]", k_x_msad}};
+        {"v_and_b32 [and]", k_x_and}, {"v_or_b32 [or]", k_x_or}, {"v_xor_b32 [xor]", k_x_xor}, {"v_lshlrev_b32 [lshl]", k_x_lshl}, {"v_sub_u32 [sub]", k_x_sub}, {"v_mov_b32 [mov]", k_x_mov}, {"v_cndmask_b32 [cndmask]", k_x_cndmask}, {"v_mul_lo_u32 [mullo]", k_x_mullo}, {"v_add3_u32 [add3]", k_x_add3}, {"v_max_f32 [maxf]", k_x_maxf}, {"v_min_f32 [minf]", k_x_minf}, {"v_med3_f32 [med3f]", k_x_med3f}, {"v_mul_f32 [mulf]", k_x_mulf}, {"v_add_f32 [addf]", k_x_addf}, {"v_cvt_f32_i32 [cvtfi]", k_x_cvtfi}, {"v_cvt_i32_f32 [cvtif]", k_x_cvtif}, {"v_mul_i32_i24 [mul24]", k_x_mul24}, {"v_mad_u32_u24 [madu24]", k_x_madu24}, {"v_bfi_b32 [bfi]", k_x_bfi}, {"v_min_i32 [mini]", k_x_mini}, {"v_add_u32 [addsg]", k_x_addsg}, {"v_mul_f32 sgpr operand [mulfsg]", k_x_mulfsg}, {"v_add_f32 sgpr operand [addfsg]", k_x_addfsg}, {"v_mov_b32 from sgpr [movsg]", k_x_movsg}, {"v_fmac_f32 sgpr operand [fmacsg]", k_x_fmacsg}, {"v_subrev_u32 [subrev]", k_x_subrev}, {"v_fmac_f32 [fmac]", k_x_fmac}, {"v_add_i16 [addi16]", k_x_addi16}, {"v_max3_i32 [max3i]", k_x_max3i}, {"v_xad_u32 [xad]", k_x_xad}, {"v_lshl_or_b32 [lshlor]", k_x_lshlor}, {"v_add_lshl_u32 [addlshl]", k_x_addlshl}, {"v_and_or_b32 [andor_v]", k_x_andor_v}, {"v_dot2c_f32_f16 [dot2f]", k_x_dot2f}, {"v_sub_i32 [sat_sub]", k_x_sat_sub}, {"v_min_u32 [minu]", k_x_minu}, {"v_pk_min_u16 [pkminu]", k_x_pkminu}, {"v_mad_u16 [mad_u16]", k_x_mad_u16}, {"v_msad_u8 [msad]", k_x_msad}};
     int *out;
     unsigned long long *cyc;
     const int nblk = 256 * 4;  // 4 blocks per CU
