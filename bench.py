@@ -435,9 +435,10 @@ def main():
         Bl = (B + lanes - 1) // lanes    # frames per launch of lane 0, the one the per-layer hipEvents time
         # dominant kernel = the conv kernel instantiation with the largest total time
         groups = {}
+        fused = ctx.pool_fused_layers()      # convs that run as k_conv_i16_pool (conv + leaky + 2x2 pool in one kernel)
         for l in net.CONVS:
             info = ctx.conv_launch_info(l.ord)
-            key = (l.size, info["pixels_per_lane"], paths[l.ord])
+            key = (l.size, "pool" if l.idx in fused else info["pixels_per_lane"], paths[l.ord])
             g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "bytes": 0.0, "steps": 0, "layers": []})
             g["ms"] += float(layer_ms[l.idx])
             g["launches"] += 1
@@ -447,7 +448,7 @@ def main():
         key, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
         avg_ms = g["ms"] / g["launches"]
         ach = (g["bytes"] / g["launches"]) / (avg_ms * 1e-3) / 1e9
-        kname = f"k_conv_i16<KS={key[0]},P={key[1]},MODE={key[2]}>"
+        kname = f"k_conv_i16_pool<MODE={key[2]}>" if key[1] == "pool" else f"k_conv_i16<KS={key[0]},P={key[1]},MODE={key[2]}>"
         conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
         # VALU issue roofline over the whole step (chip level, independent of how launches overlap):
         # SIMD issue cycles the conv steps of one batch need at the measured instruction costs
@@ -471,7 +472,7 @@ def main():
                             "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
                             "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
         traffic, traffic_src = hbm_traffic_per_launch(key[0], B)
-        fam = [l for l in net.CONVS if l.size == key[0]]     # the scope of `traffic`: all launches of this kernel size
+        fam = [l for l in net.CONVS if l.size == key[0] and l.idx not in fused]     # the scope of `traffic`: all k_conv_i16 launches of this kernel size
         fam_alg = sum(conv_layer_bytes(l, Bl) for l in fam) / len(fam)
         result = {
             "metric": "YOLOv2 INT16 416x416 frames/sec", "value": fps, "unit": "frames/s",
@@ -481,7 +482,7 @@ def main():
             "config": {"workload": f"YOLOv2 INT16 416x416 batch={B} per GPU, bit-exact int16 conv/bias/leaky/maxpool/reorg path",
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded x{world}, weights broadcast once",
                        "conv_paths": paths, "conv_path_block_counts": ctx.layer_path_counts(),
-                       "lanes": lanes, "frames_per_launch": Bl},
+                       "lanes": lanes, "frames_per_launch": Bl, "conv_pool_fused_layers": fused},
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

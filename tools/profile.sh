@@ -7,10 +7,10 @@ TAG=$1; shift
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 bench.py --no-cpu-baseline "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -- python3 bench.py --no-cpu-baseline --no-sub-records "$@" > "$OUT/bench.json" 2> "$OUT/bench.err" || { tail -20 "$OUT/bench.err"; exit 1; }
 STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 {
-  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline $*"
+  echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-sub-records $*"
   echo "# bench line:"; tail -1 "$OUT/bench.json"
   echo "# kernel stats of the WHOLE run (weight load, set_batch autotune launches of every tile shape, warm-up and timed steps):"
   python3 - "$STATS" <<'PY'

@@ -18,13 +18,15 @@ def short(name):
     n = name.replace("HIP_vector_type<int, 2u>", "int2").split("(")[0].replace("void ", "").strip()
     if n.startswith("y2::k_conv_i16_splitk<"):
         return "y2::k_conv_i16_splitk<KS=" + n.split("<")[1].split(",")[0] + ">"
+    if n.startswith("y2::k_conv_i16_pool<"):
+        return "y2::k_conv_i16_pool<...>"
     if n.startswith("y2::k_conv_i16<"):
         return "y2::k_conv_i16<KS=" + n.split("<")[1].split(",")[0] + ",...>"
     return n
 
 
-def load(cnt, n):
-    f = glob.glob(os.path.join(out, f"{cnt}_{n}", "**", "*counter_collection.csv"), recursive=True)[0]
+def load(cnt, n, prefix=""):
+    f = glob.glob(os.path.join(out, f"{prefix}{cnt}_{n}", "**", "*counter_collection.csv"), recursive=True)[0]
     val = collections.defaultdict(float)
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
@@ -45,21 +47,37 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
             continue   # launched at load / autotune only, or the autotune pick differed between the passes
         e = res.setdefault(k, {"launches_per_step": dc // 4})
         e[cnt + "_KB_per_launch"] = (v6[k] - v2.get(k, 0.0)) / dc
-# known bytes of the five maxpool layers (logical, unpadded): calibration of the x2 FETCH correction
+# known bytes of the five maxpool layers (logical, unpadded): calibration of the x2 FETCH correction, from the
+# calibration pass pair (YOLO2_NO_POOLFUSE=1: all five pools run as k_maxpool2)
 pool_in = sum(l.c * l.h * l.w for l in net.LAYERS if l.type == net.MAXPOOL) * 2 * batch
-pool_out = sum(l.c * l.out_h * l.out_w for l in net.LAYERS if l.type == net.MAXPOOL) * 2 * batch
 cal = None
-if "y2::k_maxpool2" in res:
-    p = res["y2::k_maxpool2"]
-    cal = {"known_read_bytes_per_step": pool_in, "FETCH_SIZE_bytes_per_step_raw": p["FETCH_SIZE_KB_per_launch"] * 1024 * p["launches_per_step"],
-           "known_write_bytes_per_step": pool_out, "WRITE_SIZE_bytes_per_step_raw": p["WRITE_SIZE_KB_per_launch"] * 1024 * p["launches_per_step"]}
-    cal["fetch_raw_over_known"] = cal["FETCH_SIZE_bytes_per_step_raw"] / pool_in
-    cal["write_raw_over_known"] = cal["WRITE_SIZE_bytes_per_step_raw"] / pool_out
+try:
+    (v2, c2), (v6, c6) = load("FETCH_SIZE", 2, "CAL_"), load("FETCH_SIZE", 6, "CAL_")
+    k = "y2::k_maxpool2"
+    dc = c6.get(k, 0) - c2.get(k, 0)
+    if dc > 0 and dc % 4 == 0:
+        raw = (v6[k] - v2.get(k, 0.0)) * 1024 / 4
+        cal = {"known_read_bytes_per_step": pool_in, "FETCH_SIZE_bytes_per_step_raw": raw, "launches_per_step": dc // 4,
+               "fetch_raw_over_known": raw / pool_in, "pass": "YOLO2_NO_POOLFUSE=1 (all five pools as k_maxpool2)"}
+except (IndexError, KeyError):
+    pass
 for k, e in res.items():
     e["hbm_bytes_per_launch"] = 2.0 * e.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024 + e.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
-doc = {"batch": batch, "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, (steps=6 - steps=2)/4; "
+import hashlib
+h = hashlib.sha256()
+d = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc")
+for f in sorted(os.listdir(d)):
+    h.update(f.encode())
+    h.update(open(os.path.join(d, f), "rb").read())
+doc = {"batch": batch, "kernel_source_hash": h.hexdigest()[:16], "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, (steps=6 - steps=2)/4; "
                                    "bytes = 2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE, KB = 1024 B",
        "calibration_on_k_maxpool2": cal, "kernels": res}
+try:
+    b = json.load(open(os.path.join(out, "FETCH_SIZE_6", "bench.json")))
+    doc["lanes"] = b["config"]["lanes"]
+    doc["conv_pool_fused_layers"] = b["config"].get("conv_pool_fused_layers")
+except (OSError, KeyError, ValueError):
+    pass
 json.dump(doc, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(cal, indent=1))
 print(f"{'kernel':58s} {'launch/step':>11s} {'fetch MB/launch (x2)':>22s} {'write MB/launch':>16s}")
