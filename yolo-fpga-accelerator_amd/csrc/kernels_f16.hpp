@@ -53,6 +53,9 @@ struct ConvF16Args {
     int oWp, oPL, npool;   // pooled tensor: row pitch, plane size (items), B * (H/2) * (W/2)
 };
 
+#ifndef Y2_ABL
+#define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile
+#endif
 constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
 constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
 
@@ -63,6 +66,23 @@ __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
     const int y = r / W;
     const int x = r - y * W;
     return b * PL + (y + 1) * Wp + x;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin in launch order (id & 7), and every XCD has its own 4 MiB L2.  With the
+// plain 1-D grid the n-tiles of one pixel tile (which stage the SAME input tile) land on different XCDs, so the input
+// crosses the fabric once per n-tile.  Re-number: XCD k owns a CONTIGUOUS range of the logical sequence (pixel tile
+// major, n-tile minor), so the n-tiles of a pixel tile meet in one L2 and the pixel tiles an XCD runs side by side share
+// each weight tile.  (Ablation on the 13x13 512->1024 layer at batch 256: removing the weight-tile fills saved 22 %;
+// Infinity-Cache / HBM traffic, not LDS, is what they cost.)
+__device__ __forceinline__ int xcd_logical_id()
+{
+#if defined(Y2_F16_NO_XCD)
+    return (int)blockIdx.x;
+#else
+    const int total = (int)gridDim.x, id = (int)blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3, q = total >> 3, r = total & 7;
+    return xcd * q + min(xcd, r) + slot;
+#endif
 }
 
 // flat item offset of MFMA row m of pixel tile `tile` (BM rows per tile)
@@ -128,11 +148,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) 
     const int HW = a.H * a.W;
     // 1-D grid, channel tile fastest: the gridDim.y... workgroups that share one pixel tile (the A
     // operand) are launched back to back, so A is fetched from HBM once and hit in L2 by the rest
-    const int q0 = (blockIdx.x / a.n_tiles) * kBM;
-    const int n0 = (blockIdx.x % a.n_tiles) * BN;
+    const int bid = xcd_logical_id();
+    const int q0 = (bid / a.n_tiles) * kBM;
+    const int n0 = (bid % a.n_tiles) * BN;
     const int KK = a.KS * a.KS;
 
-    const int tile = blockIdx.x / a.n_tiles;
+    const int tile = bid / a.n_tiles;
     for (int i = tid; i < kBM; i += NT) fo_s[i] = tile_row_flat(a, tile, kBM, i);
     __syncthreads();
 
@@ -314,11 +335,12 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int HW = a.H * a.W;
-    const int q0 = (blockIdx.x / a.n_tiles) * BM;
-    const int n0 = (blockIdx.x % a.n_tiles) * BN;
+    const int bid = xcd_logical_id();
+    const int q0 = (bid / a.n_tiles) * BM;
+    const int n0 = (bid % a.n_tiles) * BN;
     const int KK = a.KS * a.KS;
 
-    const int tile = blockIdx.x / a.n_tiles;
+    const int tile = bid / a.n_tiles;
     if (tid < BM) fo_s[tid] = tile_row_flat(a, tile, BM, tid);
     __syncthreads();
 
@@ -491,8 +513,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int HW = a.H * a.W;
-    const int q0 = (blockIdx.x / a.n_tiles) * BM;
-    const int n0 = (blockIdx.x % a.n_tiles) * BN;
+    const int bid = xcd_logical_id();
+    const int q0 = (bid / a.n_tiles) * BM;
+    const int n0 = (bid % a.n_tiles) * BN;
     const int d0 = q0 - a.W - 1;                 // pixel index of LDS row 0
     const int NA = lt_rows / 8 - 1;              // 8-row groups filled by DMA; the last group is the zero rows
     const int zrow = NA * 8;
@@ -572,6 +595,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+#ifdef Y2_HALO_PRIO
+    // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4: the later-dispatched half of a big workgroup loses every
+    //  arbitration at equal priority; a static s_setprio 1 for it before the main loop)
+    if (NW == 16 && wave >= NW / 2) __builtin_amdgcn_s_setprio(Y2_HALO_PRIO);
+#endif
     int step = 0, cur = 0;                // cur = step % NB
     int n_tap = NB - 1, n_c0 = 0;         // (tap, channel offset) of step + NB - 1
     // (fetching the next tap's first A fragments ahead of the barrier that ends a tap was tried: -1 %)
@@ -583,7 +611,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bool more = step + NB - 1 < nsteps;
             if (more) {
+#if (Y2_ABL & 8)
+                fill_b(cur == 0 ? NB - 1 : cur - 1, 0, 0);          // diagnostic: always the same (cache-hot) weight tile
+#elif !(Y2_ABL & 2)
                 fill_b(cur == 0 ? NB - 1 : cur - 1, n_tap, n_c0);   // buffer (step + NB - 1) % NB: last read in step - 1
+#endif
                 if (++n_tap == 9) { n_tap = 0; n_c0 += BK; }
             }
             const int toff = (tap / 3 - 1) * a.W + (tap % 3 - 1);
@@ -606,11 +638,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
             read_frags(0, 0);
 #pragma unroll
             for (int kk = 0; kk < BK / 16; ++kk) {
+#if (Y2_ABL & 1)
+                if (kk + 1 < BK / 16) { af[(kk + 1) & 1][0] = af[kk & 1][0]; af[(kk + 1) & 1][MT - 1] = af[kk & 1][MT - 1]; bf[(kk + 1) & 1][0] = bf[kk & 1][0]; bf[(kk + 1) & 1][1] = bf[kk & 1][1]; }
+#else
                 if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
+#endif
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
+#if (Y2_ABL & 4)
+                        if (kk == 0)
+#endif
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
             }
             // interleave: the fragment reads of k-slice kk+1 go out between the MFMAs of slice kk
