@@ -184,3 +184,28 @@ def test_multi_images_entry_and_rank_api_with_rccl():
     assert np.array_equal(f32.reshape(-1).view(np.uint32), FULL["f32/std/region_raw_f32"].view(np.uint32))
     ctx.rccl_finalize()
     ctx.close()
+
+
+def test_c5_batch2048_sharded_over_eight_contexts_on_one_gpu():
+    """configs[4] rehearsed on the one GPU of this box: 2048 frames frame-sharded over EIGHT contexts (device list
+    [0]*8, so RCCL is replaced by device-to-device copies; the sharding, the per-device host threads, the 256-frame
+    shards with their two 128-frame lanes and the streaming entry are the real ones).  Frames of period 8: every frame of
+    every shard equals the period's reference result (frame 0 = the compiled reference's fixture), i.e. the result does
+    not depend on which shard or which position a frame lands in."""
+    model = synth.SynthModel(seed=1)
+    base = np.concatenate([synth.frames(7, 1), synth.frames(4000, 7)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    want, q0 = ctx.run_batch_host(base)
+    ctx.close()
+    assert np.array_equal(want[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    frames = np.broadcast_to(base[None], (256, 8, 3, 416, 416)).reshape(2048, 3, 416, 416)      # 4.25 GB of floats
+    frames = np.ascontiguousarray(frames)
+    m = hipdrv.Yolo2HipMulti([0] * 8)
+    m.load_model(model)
+    assert [hipdrv.shard_range(2048, r, 8) for r in (0, 7)] == [(0, 256), (1792, 2048)]
+    got, q = m.run_frames(frames, batch_per_device=256)
+    m.close()
+    assert q == q0 and got.shape == (2048, 425, 13, 13)
+    g = got.reshape(256, 8, -1)
+    assert np.array_equal(g, np.broadcast_to(want.reshape(1, 8, -1), g.shape))
