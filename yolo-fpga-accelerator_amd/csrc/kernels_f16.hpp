@@ -51,13 +51,61 @@ struct ConvF16Args {
     // to the POOLED tensor (geometry below) and the full-resolution tensor is never written
     int pool;              // 0 / 1
     int oWp, oPL, npool;   // pooled tensor: row pitch, plane size (items), B * (H/2) * (W/2)
+    // division by H*W and by W as multiply-high + shift (set_fast_div): the generic 32-bit division the compiler emits
+    // is ~30 instructions, and a halo-kernel lane needs 14 of them before its first MFMA
+    unsigned mHW, sHW, mW, sW;
+    int stamp;             // diagnostic builds (-DY2_STAMPS): this launch records its workgroups' timeline in y2_stamps
 };
+
+// Granlund-Montgomery round-up division: exact for every 32-bit numerator, divisor >= 2
+inline void fast_div_magic(unsigned d, unsigned &m, unsigned &s)
+{
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    s = l - 1;
+}
+inline void set_fast_div(ConvF16Args &a)
+{
+    fast_div_magic((unsigned)(a.H * a.W), a.mHW, a.sHW);
+    fast_div_magic((unsigned)a.W, a.mW, a.sW);
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s)
+{
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> 1)) >> s;
+}
+// (b, y, x) of pixel index q
+__device__ __forceinline__ void pixel_of(const ConvF16Args &a, int q, int &b, int &y, int &x)
+{
+    b = (int)fast_div((unsigned)q, a.mHW, a.sHW);
+    const int r = q - b * (a.H * a.W);
+    y = (int)fast_div((unsigned)r, a.mW, a.sW);
+    x = r - y * a.W;
+}
+__device__ __forceinline__ int flat_of_fast(const ConvF16Args &a, int q)
+{
+    int b, y, x;
+    pixel_of(a, q, b, y, x);
+    return b * a.PL + (y + 1) * a.Wp + x;
+}
 
 #ifndef Y2_ABL
 #define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile
 #endif
 constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
 constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
+
+#ifdef Y2_STAMPS
+// In-kernel timeline of the halo kernel's workgroups (diagnostic build only; read back by yolo2_hip_debug_stamps):
+// per workgroup 8 x u64 = {s_memrealtime at entry, s_memtime at entry, after the set-up, after the prologue fills landed,
+// after the main loop, after the epilogue, HW_ID, s_memrealtime at exit}.  No output value depends on a stamp.
+constexpr int kStampWGs = 16384;
+__device__ unsigned long long y2_stamps[kStampWGs * 8];
+#define Y2_STAMP(slot) do { if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) y2_stamps[(size_t)blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define Y2_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ int flat_of_h(int q, int HW, int W, int Wp, int PL)
 {
@@ -512,7 +560,14 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int HW = a.H * a.W;
+#ifdef Y2_STAMPS
+    if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) {
+        y2_stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        y2_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |          // HW_ID: cu_id [11:8], sh [12], se [15:13]
+                                                ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);   // XCC_ID
+    }
+#endif
+    Y2_STAMP(1);
     const int bid = xcd_logical_id();
     const int q0 = (bid / a.n_tiles) * BM;
     const int n0 = (bid % a.n_tiles) * BN;
@@ -520,7 +575,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     const int NA = lt_rows / 8 - 1;              // 8-row groups filled by DMA; the last group is the zero rows
     const int zrow = NA * 8;
 
-    if (tid < BM) fo_s[tid] = flat_of_h(min(q0 + tid, a.npix - 1), HW, a.W, a.Wp, a.PL);
+    if (tid < BM) fo_s[tid] = flat_of_fast(a, min(q0 + tid, a.npix - 1));
     if (tid < 2 * 8 * 8) {                       // zero rows of both buffers: 2 x 8 rows x 128 B = 128 x 16 B
         const int buf = tid >> 6, r = (tid >> 3) & 7, c = tid & 7;
         *reinterpret_cast<int4 *>(As + ((size_t)buf * lt_rows + zrow + r) * ROWH + c * 8) = make_int4(0, 0, 0, 0);
@@ -529,33 +584,38 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 
     const int lrow = lane >> 3, lslot = lane & 7;
     const int a_iters = (NA + NW - 1) / NW;
-    size_t a_src[kMaxAIters];                    // source of this lane's 16 bytes in each of its A fill instructions
+    // Per-lane sources as 32-bit BYTE offsets from a wave-uniform base (the tensors stay below 4 GiB: checked by the
+    // host): the LDS-DMA instruction then takes `saddr + 32-bit voffset` instead of a 64-bit address per lane, which
+    // halves what its issue has to move.
+    unsigned a_src[kMaxAIters];                  // source of this lane's 16 bytes in each of its A fill instructions
 #pragma unroll
     for (int it = 0; it < kMaxAIters; ++it) {
         const int row = (wave + it * NW) * 8 + lrow;
         const int d = min(max(d0 + row, 0), a.npix - 1);     // rows outside the tensor are only ever read masked
-        a_src[it] = ((size_t)kLead + flat_of_h(d, HW, a.W, a.Wp, a.PL)) * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+        a_src[it] = (unsigned)((((size_t)kLead + flat_of_fast(a, d)) * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8)) * 2);
     }
-    size_t b_src[BG];
+    unsigned b_src[BG];
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
         const int row = (wave * BG + i) * 8 + lrow;
-        b_src[i] = (size_t)(n0 + row) * 9 * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8);
+        b_src[i] = (unsigned)(((size_t)row * 9 * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8)) * 2);
     }
+    const char *wbase = reinterpret_cast<const char *>(wh + (size_t)n0 * 9 * a.Cp_in);   // this n-tile's weights (uniform)
     auto fill_a = [&](int buf, int c0) {        // the whole halo tile of one 64-channel chunk
+        const char *abase = reinterpret_cast<const char *>(act + c0);
 #pragma unroll
         for (int it = 0; it < kMaxAIters; ++it) {
             const int g = wave + it * NW;
             if (it < a_iters && g < NA)
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(act + a_src[it] + c0),
+                __builtin_amdgcn_global_load_lds((glb_void_t *)(abase + a_src[it]),
                                                  (lds_void_t *)(As + ((size_t)buf * lt_rows + g * 8) * ROWH), 16, 0, 0);
         }
     };
     auto fill_b = [&](int buf, int tap, int c0) {
-        const long bo = (long)tap * a.Cp_in + c0;
+        const char *bb = wbase + ((long)tap * a.Cp_in + c0) * 2;
 #pragma unroll
         for (int i = 0; i < BG; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(wh + b_src[i] + bo),
+            __builtin_amdgcn_global_load_lds((glb_void_t *)(bb + b_src[i]),
                                              (lds_void_t *)(Bs + ((size_t)buf * BN + (wave * BG + i) * 8) * ROWH), 16, 0, 0);
     };
 
@@ -574,7 +634,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     for (int t = 0; t < MT; ++t) {
         const int m = wm * (32 * MT) + t * 32 + frow;
         lo[t] = m + a.W + 1;
-        const int q = min(q0 + m, a.npix - 1), rem = q % HW, y = rem / a.W, x = rem - y * a.W;
+        int bq, y, x;
+        pixel_of(a, min(q0 + m, a.npix - 1), bq, y, x);
         unsigned mk = 0;
 #pragma unroll
         for (int tp = 0; tp < 9; ++tp) {
@@ -589,11 +650,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 
     const int csteps = a.Cp_in / BK;
     const int nsteps = csteps * 9;
+    Y2_STAMP(2);
     fill_a(0, 0);
     fill_b(0, 0, 0);
     if (NB == 3) fill_b(1, 1, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    Y2_STAMP(3);
 
 #ifdef Y2_HALO_PRIO
     // (MI355X_MICROARCH.md, "Two waves per SIMD", item 4: the later-dispatched half of a big workgroup loses every
@@ -610,6 +673,8 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bool more = step + NB - 1 < nsteps;
+            // (Issuing this fill after the MFMAs of the first or second k-slice instead - so that the sixteen wavefronts do
+            //  not queue their pieces at once straight after the barrier - measured -1.7 % / -3 %: the fill then lands late.)
             if (more) {
 #if (Y2_ABL & 8)
                 fill_b(cur == 0 ? NB - 1 : cur - 1, 0, 0);          // diagnostic: always the same (cache-hot) weight tile
@@ -669,6 +734,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
         }
     }
 
+    Y2_STAMP(4);
     // epilogue: bias + leaky, transposed through LDS into 16-byte stores (the staging arena is free now)
     _Float16 (*Ct)[kCt] = reinterpret_cast<_Float16 (*)[kCt]>(smem_h);
     int fo_r[BM / (NT / (BN / 8))];   // fo_s lives behind the arena the Ct tile may overlap: keep what this thread needs
@@ -701,6 +767,11 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
             *reinterpret_cast<half8_t *>(out + ((size_t)kLead + fo_r[rr]) * a.Cp_out + a.out_ch_off + ch0) = v;
         }
     }
+#ifdef Y2_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Y2_STAMP(5);
+    if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) y2_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:

@@ -2524,6 +2524,12 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             a.leaky = l.leaky;
             a.KS = l.size;
             a.pool = 0; a.oWp = a.oPL = a.npool = 0;
+            set_fast_div(a);
+#ifdef Y2_STAMPS
+            a.stamp = getenv("YOLO2_STAMP_LAYER") && atoi(getenv("YOLO2_STAMP_LAYER")) == i;
+#else
+            a.stamp = 0;
+#endif
             const _Float16 *wp = (const _Float16 *)(c->wh + c->wh_off[ord]);
             const float *bp = (const float *)(c->biasf + c->biasf_off[ord]);
             _Float16 *op = i == 30 ? (_Float16 *)nullptr : tout.d;
@@ -2562,7 +2568,9 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                     const bool three = lds128 <= cap;
                     // (the two-buffer 256x128 form that would fit the 104x104 layers runs one workgroup per CU and measured
                     //  6 % slower there than the 128x128 kernel with two: only the shapes below are used)
-                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three);
+                    // (the kernel addresses its tensors with 32-bit byte offsets from a uniform base)
+                    const bool off32 = ((size_t)kLead + (size_t)B * a.PL) * a.Cp_in * 2 < (1ull << 32);
+                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three) && off32;
                     if (fits) {   // (the kernels' dynamic-LDS limit was raised for this device in load_weights_fp32)
                         if (wide) {
                             a.n_tiles = l.n / 256;
@@ -2616,6 +2624,15 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     if (ev) c->prof_runs++;
     return YOLO2_SUCCESS;
 }
+
+#ifdef Y2_STAMPS
+// diagnostic build only: the halo kernel's workgroup timeline of the launch selected by YOLO2_STAMP_LAYER
+extern "C" int yolo2_hip_debug_stamps(unsigned long long *dst, int n_wg)
+{
+    if (n_wg > kStampWGs) n_wg = kStampWGs;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y2_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *c, const float *frames, int batch, float *region)
 {
