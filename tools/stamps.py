@@ -30,13 +30,24 @@ def main():
     used = buf[:, 1] != 0
     b = buf[used].astype(np.int64)
     print(f"layer {layer}: {len(b)} workgroups stamped")
-    ph = {"set-up": b[:, 2] - b[:, 1], "prologue fill": b[:, 3] - b[:, 2], "main loop": b[:, 4] - b[:, 3], "epilogue": b[:, 5] - b[:, 4],
-          "total": b[:, 5] - b[:, 1]}
+    persistent = (b[:, 6] < 4096).all()       # the persistent kernel stores its tile count there, k_conv_f16_halo the HW_ID
+    if persistent:
+        nt = np.maximum(b[:, 6], 1)
+        print(f"  persistent workgroups: {int(nt.min())}..{int(nt.max())} tiles each")
+        ph = {"set-up + first fill": b[:, 2] - b[:, 1], "first tile loop": b[:, 3] - b[:, 2], "first tile epilogue": b[:, 4] - b[:, 3],
+              "total": b[:, 5] - b[:, 1], "total / tiles": (b[:, 5] - b[:, 1]) // nt}
+    else:
+        ph = {"set-up": b[:, 2] - b[:, 1], "prologue fill": b[:, 3] - b[:, 2], "main loop": b[:, 4] - b[:, 3], "epilogue": b[:, 5] - b[:, 4],
+              "total": b[:, 5] - b[:, 1]}
     for k, v in ph.items():
         print(f"  {k:14s} median {int(np.median(v)):8d}  p10 {int(np.percentile(v, 10)):8d}  p90 {int(np.percentile(v, 90)):8d} cycles")
     real = (b[:, 7] - b[:, 0])   # 100 MHz ticks
     clk = np.median((b[:, 5] - b[:, 1]) / np.maximum(real, 1)) * 100.0
     print(f"  in-kernel clock ~ {clk:.0f} MHz")
+    if persistent:
+        span = (b[:, 7].max() - b[:, 0].min()) * 10.0 / 1000.0
+        print(f"  kernel span {span:.1f} us")
+        return
     # succession on a CU: key = (xcc, se, sh, cu)
     hw = b[:, 6] & 0xFFFFFFFF; xcc = (b[:, 6] >> 32) & 0xF
     key = (xcc << 16) | (hw & 0xFF00)

@@ -364,6 +364,15 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64 < 256 ? 256 : (BM / 64) 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
+// One LDS-DMA piece (64 lanes x 16 B) from `base + off` (wave-uniform base, 32-bit byte offset per lane).  The empty asm
+// keeps the zero-extension of `off` in the block of the load: instruction selection then picks the `saddr + voffset` form;
+// with the extension hoisted out of a loop it falls back to a 64-bit address per lane (an add and two registers per piece).
+__device__ __forceinline__ void lds_dma16(const char *base, unsigned off, _Float16 *lds)
+{
+    asm volatile("" : "+v"(off));
+    __builtin_amdgcn_global_load_lds((glb_void_t *)(base + off), (lds_void_t *)lds, 16, 0, 0);
+}
+
 template <int BN>
 __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
@@ -539,7 +548,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
 // straddled an image-row end its rows skipped one and 39 % of the LDS cycles were bank conflicts.)
 // A dense tile has no zeros for out-of-image taps, so a lane whose tap leaves the image reads a
 // dedicated all-zero row instead (one v_cndmask on the address; identical addresses broadcast).
-template <int BN, int NB, int NW = 8>
+template <int BN, int NB, int NW = 8, int TS = 32>
 __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                         const ConvF16Args a, const int lt_rows)
@@ -548,11 +557,16 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     // BN = 128: 4 x 2 wavefronts of 64 x 64, NB = 3 weight-tile buffers;
     // BN = 256: 2 x 4 wavefronts of 128 x 64 (NW = 8) or 4 x 4 of 64 x 64 (NW = 16: four wavefronts per SIMD fill the
     //           bubbles around the per-tap barrier better, +4 %), NB = 2
-    constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / 32;
+    // TS = 32: v_mfma_f32_32x32x16_f16; TS = 16: v_mfma_f32_16x16x32_f16 - the same FLOPs per cycle and the same LDS bytes
+    // per wavefront tile, but the chip, which holds its clock down under this load (~1.75 GHz), holds a higher clock on
+    // the small shape (MI355X_MICROARCH.md, DVFS give-back item 7)
+    constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / TS, NJ = 64 / TS;   // MT x NJ MFMA tiles per wavefront
+    constexpr int KQ = 64 / TS, KSL = 8 * KQ, NKS = BK / KSL;                     // lanes' k-groups, k per MFMA, MFMA k-slices per step
+    typedef float acc_t __attribute__((ext_vector_type(TS == 32 ? 16 : 4)));
     constexpr int BG = BN / 8 / NW;                                // B fill instructions per wavefront and tap
     constexpr int kCt = BN + 8;                                    // halves per row of the epilogue staging tile
     constexpr int kMaxAIters = 64 / NW;                            // A fill instructions per wavefront (host: lt_rows <= 64*8 + 8)
-    static_assert((MT == 2 || MT == 4) && BG >= 1 && (NB == 2 || NB == 3) && (NW == 8 || NW == 16), "tile shape");
+    static_assert((MT * TS == 64 || MT * TS == 128) && (TS == 32 || TS == 16) && BG >= 1 && (NB == 2 || NB == 3) && (NW == 8 || NW == 16), "tile shape");
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
     _Float16 *As = smem_h;                                   // [2][lt_rows][64]; rows lt_rows-8.. of each buffer stay zero
     _Float16 *Bs = smem_h + (size_t)2 * lt_rows * ROWH;      // [NB][BN][64]: with NB = 3 the weight tile of tap t+2 is in flight while t is multiplied
@@ -607,32 +621,30 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
         for (int it = 0; it < kMaxAIters; ++it) {
             const int g = wave + it * NW;
             if (it < a_iters && g < NA)
-                __builtin_amdgcn_global_load_lds((glb_void_t *)(abase + a_src[it]),
-                                                 (lds_void_t *)(As + ((size_t)buf * lt_rows + g * 8) * ROWH), 16, 0, 0);
+                lds_dma16(abase, a_src[it], As + ((size_t)buf * lt_rows + g * 8) * ROWH);
         }
     };
     auto fill_b = [&](int buf, int tap, int c0) {
         const char *bb = wbase + ((long)tap * a.Cp_in + c0) * 2;
 #pragma unroll
         for (int i = 0; i < BG; ++i)
-            __builtin_amdgcn_global_load_lds((glb_void_t *)(bb + b_src[i]),
-                                             (lds_void_t *)(Bs + ((size_t)buf * BN + (wave * BG + i) * 8) * ROWH), 16, 0, 0);
+            lds_dma16(bb, b_src[i], Bs + ((size_t)buf * BN + (wave * BG + i) * 8) * ROWH);
     };
 
-    float16_t acc[MT][2];
+    acc_t acc[MT][NJ];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < (TS == 32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
 
-    const int frow = lane & 31, fhalf = lane >> 5;
+    const int frow = lane & (TS - 1), fhalf = lane / TS;   // fragment row, k-group (8 halves) of this lane
     int lo[MT];                                  // LDS row of this lane's A rows at the centre tap
     unsigned tapmask[MT];                        // bit t: tap t of that pixel lies inside the image
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
-        const int m = wm * (32 * MT) + t * 32 + frow;
+        const int m = wm * (TS * MT) + t * TS + frow;
         lo[t] = m + a.W + 1;
         int bq, y, x;
         pixel_of(a, min(q0 + m, a.npix - 1), bq, y, x);
@@ -644,9 +656,9 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
         }
         tapmask[t] = mk;
     }
-    int brow[2];
+    int brow[NJ];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) brow[t] = wn * 64 + t * 32 + frow;
+    for (int t = 0; t < NJ; ++t) brow[t] = wn * 64 + t * TS + frow;
 
     const int csteps = a.Cp_in / BK;
     const int nsteps = csteps * 9;
@@ -691,40 +703,57 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
                 asw[t] = (arow[t] >> 1) & 7;
             }
             const _Float16 *Bt = Bs + (size_t)cur * BN * ROWH;
-            half8_t af[2][MT], bf[2][2];
+            half8_t af[TS == 32 ? 2 : 1][MT], bf[TS == 32 ? 2 : 1][NJ];
             auto read_frags = [&](int kk, int set) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    af[set][t] = *reinterpret_cast<const half8_t *>(At + (size_t)arow[t] * ROWH + (((kk * 2 + fhalf) ^ asw[t]) * 8));
+                    af[set][t] = *reinterpret_cast<const half8_t *>(At + (size_t)arow[t] * ROWH + (((kk * KQ + fhalf) ^ asw[t]) * 8));
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    bf[set][t] = *reinterpret_cast<const half8_t *>(Bt + (size_t)brow[t] * ROWH + (((kk * 2 + fhalf) ^ ((brow[t] >> 1) & 7)) * 8));
+                for (int t = 0; t < NJ; ++t)
+                    bf[set][t] = *reinterpret_cast<const half8_t *>(Bt + (size_t)brow[t] * ROWH + (((kk * KQ + fhalf) ^ ((brow[t] >> 1) & 7)) * 8));
             };
+            // (TS = 16: eight fragments per k-slice - a second set for the next slice does not fit 128 registers beside the 64
+            //  accumulators, so each slice's reads are issued when the previous slice's MFMAs have their operands; the other
+            //  three wavefronts of the SIMD cover the wait)
+            constexpr bool kDouble = TS == 32;
             read_frags(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < BK / 16; ++kk) {
+            for (int kk = 0; kk < NKS; ++kk) {
+                if constexpr (!kDouble) {
+                    if (kk > 0) read_frags(kk, 0);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[0][i], bf[0][j], acc[i][j], 0, 0, 0);
+                    continue;
+                }
 #if (Y2_ABL & 1)
-                if (kk + 1 < BK / 16) { af[(kk + 1) & 1][0] = af[kk & 1][0]; af[(kk + 1) & 1][MT - 1] = af[kk & 1][MT - 1]; bf[(kk + 1) & 1][0] = bf[kk & 1][0]; bf[(kk + 1) & 1][1] = bf[kk & 1][1]; }
+                if (kk + 1 < NKS) { af[(kk + 1) & 1][0] = af[kk & 1][0]; af[(kk + 1) & 1][MT - 1] = af[kk & 1][MT - 1]; bf[(kk + 1) & 1][0] = bf[kk & 1][0]; bf[(kk + 1) & 1][1] = bf[kk & 1][1]; }
 #else
-                if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
+                if (kk + 1 < NKS) read_frags(kk + 1, (kk + 1) & 1);
 #endif
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < NJ; ++j)
 #if (Y2_ABL & 4)
                         if (kk == 0)
 #endif
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                    {
+                        if constexpr (TS == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                    }
             }
             // interleave: the fragment reads of k-slice kk+1 go out between the MFMAs of slice kk
-            __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
+            if constexpr (kDouble) {
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NJ, 0);
 #pragma unroll
-            for (int kk = 0; kk + 1 < BK / 16; ++kk) {
-                __builtin_amdgcn_sched_group_barrier(0x100, MT + 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
+                for (int kk = 0; kk + 1 < NKS; ++kk) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NJ, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NJ, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, MT * NJ, 0);
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, MT * 2, 0);
             // Loads return in order: all but the weight tile issued in THIS step (BG instructions per wave) have
             // landed, i.e. step + 1's weight tile and, in a chunk's first tap, the next chunk's input tile.
             if (more && NB == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BG) : "memory");
@@ -744,14 +773,15 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) fo_r[rr] = fo_s[r0 + rr * ROWS_PER_PASS];
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < NJ; ++j) {
+        const int col = wn * 64 + j * TS + frow;
         const float bv = bias[n0 + col];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            for (int r = 0; r < (TS == 32 ? 16 : 4); ++r) {
+                // D layout: 32x32: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); 16x16: row = r + 4 (lane >> 4); column = lane % TS
+                const int row = wm * (TS * MT) + i * TS + (TS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fhalf : r + 4 * fhalf);
                 float v = acc[i][j][r] + bv;
                 if (a.leaky && v < 0.f) v *= 0.1f;
                 Ct[row][col] = (_Float16)v;
@@ -772,6 +802,452 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
     Y2_STAMP(5);
     if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) y2_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// ---- persistent halo-tile kernel ----------------------------------------------------------------
+// tools/stamps.py on k_conv_f16_halo (profiles/r02_f16_halo_wg_timeline.txt): a workgroup spends ~3.0k cycles setting up,
+// ~4.3k waiting for its first tiles, ~9.6k in the LDS-transposed epilogue, and the CU then sits ~1.3 us until the next
+// 1024-thread workgroup starts - ~19k cycles per tile that no MFMA covers, 28 % of a 52x52 tile's life, 16 % at 26x26.
+// Here the workgroup is PERSISTENT and the (tile, chunk, tap) steps of all its tiles form one sequence through the same
+// two input-tile buffers and two weight-tile buffers: the next tile's first input tile is staged during this tile's
+// last chunk, its first weight tile during this tile's last tap, and the epilogue needs no LDS (operands swapped: a lane
+// ends up with 4 consecutive channels of a pixel, see k_gemm1_f16_p), so the next tile's MFMAs start while the stores
+// drain.  Same dense input tile, swizzle and zero-row masking as k_conv_f16_halo.  NB = 2.
+template <int BN, int NW, int TS>
+__global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+                                                          const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                          const ConvF16Args a, const int lt_rows, const int n_tile_total)
+{
+    constexpr int BM = 256, BK = 64, ROWH = BK;
+    constexpr int WN = BN / 64, WM = NW / WN, MT = BM / WM / TS, NJ = 64 / TS;   // MT x NJ MFMA tiles per wavefront (64 x 64)
+    constexpr int KQ = 64 / TS, KSL = 8 * KQ, NKS = BK / KSL;                     // lanes' k-groups, k per MFMA, k-slices per step
+    constexpr int NR = TS == 32 ? 16 : 4;                                         // accumulator registers per MFMA tile
+    typedef float acc_t __attribute__((ext_vector_type(NR)));
+    constexpr int BG = BN / 8 / NW, kMaxAIters = 64 / NW;
+    constexpr bool kDouble = TS == 32;                                            // second fragment set (see k_conv_f16_halo)
+    static_assert(MT * TS == 64 && BG >= 1 && (NW == 8 || NW == 16), "tile shape");
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    _Float16 *As = smem_h;                                   // [2][lt_rows][64]; rows lt_rows-8.. of each buffer stay zero
+    _Float16 *Bs = smem_h + (size_t)2 * lt_rows * ROWH;      // [2][BN][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int NA = lt_rows / 8 - 1, zrow = NA * 8;
+    const int xcd = (int)blockIdx.x & 7, S = (int)gridDim.x >> 3;
+    const int t_first = (int)((long)n_tile_total * xcd / 8) + ((int)blockIdx.x >> 3);
+    const int t_end = (int)((long)n_tile_total * (xcd + 1) / 8);
+    const int my_n = t_first < t_end ? (t_end - t_first + S - 1) / S : 0;
+    if (my_n == 0) return;
+#ifdef Y2_STAMPS
+    if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) {   // slots: 0 real start, 1 start, 2 first tiles staged, 3 / 4 first tile's loop / epilogue done, 5 end, 6 tiles, 7 real end
+        y2_stamps[(size_t)blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        y2_stamps[(size_t)blockIdx.x * 8 + 6] = (unsigned long long)my_n;
+    }
+#endif
+    Y2_STAMP(1);
+    const int csteps = a.Cp_in / BK, tile_steps = csteps * 9, total_steps = my_n * tile_steps, total_chunks = my_n * csteps;
+
+    if (tid < 2 * 8 * 8) {                       // zero rows of both input buffers
+        const int buf = tid >> 6, r = (tid >> 3) & 7, c = tid & 7;
+        *reinterpret_cast<int4 *>(As + ((size_t)buf * lt_rows + zrow + r) * ROWH + c * 8) = make_int4(0, 0, 0, 0);
+    }
+
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int a_iters = (NA + NW - 1) / NW;
+    unsigned b_src[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave * BG + i) * 8 + lrow;
+        b_src[i] = ((unsigned)row * 9u * (unsigned)a.Cp_in + (unsigned)((lslot ^ ((row >> 1) & 7)) * 8)) * 2u;
+    }
+    // ---- producers: the input tile of chunk (fa_i, fa_c) and the weight tile of step (fb_i, fb_c, fb_tap)
+    // (The per-lane source offsets of the input tile are recomputed at every fill - ~60 VALU instructions per nine taps -
+    //  rather than kept: with them live across the tap loop the 16-wavefront shape no longer fits its 128 registers.)
+    int fa_i = 0, fa_c = 0, fa_buf = 0, chunks_issued = 0;
+    auto fill_a = [&]() {
+        const char *abase = reinterpret_cast<const char *>(act + fa_c * BK);
+        const int t = t_first + fa_i * S, d0 = (t / a.n_tiles) * BM - a.W - 1;
+        int lr = lrow, ls = lslot;
+        asm volatile("" : "+v"(lr), "+v"(ls));   // (keeps the per-piece row / swizzle terms from being hoisted out of the tile loop and spilled)
+#pragma unroll
+        for (int it = 0; it < kMaxAIters; ++it) {
+            const int g = wave + it * NW;
+            if (it < a_iters && g < NA) {
+                const int row = g * 8 + lr;
+                const int d = min(max(d0 + row, 0), a.npix - 1);     // rows outside the tensor are only ever read masked
+                const unsigned src = ((unsigned)(kLead + flat_of_fast(a, d)) * (unsigned)a.Cp_in + (unsigned)((ls ^ ((row >> 1) & 7)) * 8)) * 2u;
+                lds_dma16(abase, src, As + ((size_t)fa_buf * lt_rows + g * 8) * ROWH);
+            }
+        }
+        fa_buf ^= 1;
+        ++chunks_issued;
+        if (++fa_c == csteps) { fa_c = 0; ++fa_i; }
+    };
+    int fb_i = 0, fb_c = 0, fb_tap = 0, fb_buf = 0, steps_issued = 0;
+    const char *fb_wbase = reinterpret_cast<const char *>(wh + (size_t)((t_first % a.n_tiles) * BN) * 9 * a.Cp_in);
+    auto fill_b = [&]() {
+        const char *bb = fb_wbase + ((long)fb_tap * a.Cp_in + fb_c * BK) * 2;
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            lds_dma16(bb, b_src[i], Bs + ((size_t)fb_buf * BN + (wave * BG + i) * 8) * ROWH);
+        fb_buf ^= 1;
+        ++steps_issued;
+        if (++fb_tap == 9) {
+            fb_tap = 0;
+            if (++fb_c == csteps) {
+                fb_c = 0;
+                ++fb_i;
+                const int t = t_first + min(fb_i, my_n - 1) * S;
+                fb_wbase = reinterpret_cast<const char *>(wh + (size_t)((t % a.n_tiles) * BN) * 9 * a.Cp_in);
+            }
+        }
+    };
+    __syncthreads();                             // zero rows written
+    fill_a();
+    fill_b();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    Y2_STAMP(2);
+
+    const int frow = lane & (TS - 1), fhalf = lane / TS;   // fragment row, k-group (8 halves) of this lane
+    int lo[MT];                                  // LDS row of this lane's pixel rows at the centre tap (the same for every tile)
+#pragma unroll
+    for (int u = 0; u < MT; ++u) lo[u] = wm * 64 + u * TS + frow + a.W + 1;
+    int brow[NJ];
+#pragma unroll
+    for (int u = 0; u < NJ; ++u) brow[u] = wn * 64 + u * TS + frow;
+
+    int cur_b = 0, cur_a = 0;
+    for (int ti = 0; ti < my_n; ++ti) {
+        const int t = t_first + ti * S, pt = t / a.n_tiles;
+        const int q0 = pt * BM, n0 = (t - pt * a.n_tiles) * BN;
+        unsigned tapmask[MT];                    // bit t: tap t of that pixel lies inside the image
+        int fr = lane;
+        asm volatile("" : "+v"(fr));             // (tile-loop invariants derived from the lane id are recomputed, not kept)
+        fr &= TS - 1;
+#pragma unroll
+        for (int u = 0; u < MT; ++u) {
+            int bq, y, x;
+            pixel_of(a, min(q0 + wm * 64 + u * TS + fr, a.npix - 1), bq, y, x);
+            unsigned mk = 0;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int yy = y + tp / 3 - 1, xx = x + tp % 3 - 1;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) mk |= 1u << tp;
+            }
+            tapmask[u] = mk;
+        }
+        acc_t acc[MT][NJ];                       // [pixel tile][channel tile]: D rows = channels, D columns = pixels
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
+
+        for (int ci = 0; ci < csteps; ++ci) {
+            if (chunks_issued < total_chunks) fill_a();     // the next chunk's input tile (possibly the next tile's first)
+            const _Float16 *At = As + (size_t)cur_a * lt_rows * ROWH;
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                if (steps_issued < total_steps) fill_b();   // the next step's weight tile
+                const int toff = (tap / 3 - 1) * a.W + (tap % 3 - 1);
+                int arow[MT], asw[MT];
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    arow[u] = ((tapmask[u] >> tap) & 1) ? lo[u] + toff : zrow;
+                    asw[u] = (arow[u] >> 1) & 7;
+                }
+                const _Float16 *Bt = Bs + (size_t)cur_b * BN * ROWH;
+                half8_t af[kDouble ? 2 : 1][MT], bf[kDouble ? 2 : 1][NJ];
+                auto read_frags = [&](int kk, int set) {
+#pragma unroll
+                    for (int u = 0; u < MT; ++u)
+                        af[set][u] = *reinterpret_cast<const half8_t *>(At + (size_t)arow[u] * ROWH + (((kk * KQ + fhalf) ^ asw[u]) * 8));
+#pragma unroll
+                    for (int u = 0; u < NJ; ++u)
+                        bf[set][u] = *reinterpret_cast<const half8_t *>(Bt + (size_t)brow[u] * ROWH + (((kk * KQ + fhalf) ^ ((brow[u] >> 1) & 7)) * 8));
+                };
+                read_frags(0, 0);
+#pragma unroll
+                for (int kk = 0; kk < NKS; ++kk) {
+                    const int set = kDouble ? (kk & 1) : 0;
+                    if constexpr (kDouble) {
+                        if (kk + 1 < NKS) read_frags(kk + 1, (kk + 1) & 1);
+                    } else {
+                        if (kk > 0) read_frags(kk, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) {
+                            if constexpr (TS == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[set][j], af[set][i], acc[i][j], 0, 0, 0);
+                            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[set][j], af[set][i], acc[i][j], 0, 0, 0);
+                        }
+                }
+                if constexpr (kDouble) {         // the fragment reads of k-slice kk+1 go out between the MFMAs of slice kk
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NJ, 0);
+#pragma unroll
+                    for (int kk = 0; kk + 1 < NKS; ++kk) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, MT + NJ, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, MT * NJ, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, MT * NJ, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                cur_b ^= 1;
+            }
+            cur_a ^= 1;
+        }
+
+        if (ti == 0) Y2_STAMP(3);
+        // ---- epilogue straight from the accumulators (no LDS; the next tile's first tiles are already staged).
+        // Bias is added AFTER the sum like in k_conv_f16_halo, so both kernels give the same bits.  The bias values of one
+        // channel tile are loaded just before use (the empty asm stops the compiler from hoisting all of them above the
+        // epilogue, which no longer fits 128 registers beside the 64 accumulators).
+        int fe = lane;
+        asm volatile("" : "+v"(fe));
+        const int fhe = fe / TS;
+        fe &= TS - 1;
+        unsigned orow[MT];                       // 32-bit byte offset of each pixel's item (output tensor below 4 GiB: host check)
+        bool qok[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int q = q0 + wm * 64 + i * TS + fe;
+            qok[i] = q < a.npix;
+            orow[i] = (unsigned)(kLead + flat_of_fast(a, min(q, a.npix - 1))) * (unsigned)(a.Cp_out * 2);
+        }
+        char *obase = reinterpret_cast<char *>(out + a.out_ch_off);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int cb = n0 + wn * 64 + j * TS;
+            int fhj = fhe;
+            asm volatile("" : "+v"(fhj));
+            float4 bv[NR / 4];                   // register r of a 32x32 tile = channel 8 (r >> 2) + 4 (lane >> 5) + (r & 3); 16x16: 4 (lane >> 4) + r
+#pragma unroll
+            for (int g = 0; g < NR / 4; ++g) bv[g] = *reinterpret_cast<const float4 *>(bias + cb + 8 * g + 4 * fhj);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                unsigned pk[NR / 4][2];
+#pragma unroll
+                for (int g = 0; g < NR / 4; ++g) {
+                    float v0 = acc[i][j][4 * g + 0] + bv[g].x, v1 = acc[i][j][4 * g + 1] + bv[g].y;
+                    float v2 = acc[i][j][4 * g + 2] + bv[g].z, v3 = acc[i][j][4 * g + 3] + bv[g].w;
+                    if (a.leaky) {
+                        v0 = v0 < 0.f ? v0 * 0.1f : v0; v1 = v1 < 0.f ? v1 * 0.1f : v1;
+                        v2 = v2 < 0.f ? v2 * 0.1f : v2; v3 = v3 < 0.f ? v3 * 0.1f : v3;
+                    }
+                    const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                    pk[g][0] = __builtin_bit_cast(unsigned, h01);
+                    pk[g][1] = __builtin_bit_cast(unsigned, h23);
+                }
+                if constexpr (TS == 32) {        // pair the lane halves' groups: 8 consecutive channels = 16 bytes per lane
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                        const uint2v s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+                        const uint2v s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+                        const int c0 = cb + 8 * (2 * pr + fhe);
+                        if (qok[i] && c0 < a.n_store) *reinterpret_cast<uint4 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                    }
+                } else {
+                    const int c0 = cb + 4 * fhe;
+                    if (qok[i] && c0 < a.n_store) *reinterpret_cast<uint2 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint2(pk[0][0], pk[0][1]);
+                }
+            }
+        }
+        if (ti == 0) Y2_STAMP(4);
+    }
+#ifdef Y2_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    Y2_STAMP(5);
+    if (a.stamp && tid == 0 && blockIdx.x < kStampWGs) y2_stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+
+// ---- 1x1 layers: persistent workgroups over a ring of staged K-steps --------------------------
+// A 1x1 layer is a plain GEMM [pixels x Cin] x [Cin x Cout] with 2 (layer 5) to 16 (layers 19/21/30) K-steps of 64
+// channels per tile: in the one-tile-per-workgroup kernels above its time is the per-tile set-up, the prologue fill
+// latency and the LDS-transposed epilogue, not the MFMAs (layer 26: 0.27 ms for 17 us of HBM traffic).  Here a
+// workgroup is PERSISTENT: it walks its share of the tiles, and the (tile, K-step) stages of all of them form ONE
+// sequence through a ring of NS LDS stage buffers, filled NS-1 stages ahead by LDS-DMA - the next tile's first stages
+// are in flight while this tile is multiplied and stored.  The epilogue uses no LDS (so it cannot collide with the
+// ring): the MFMA operands are swapped (weights as the row operand), which leaves every lane with 4 CONSECUTIVE
+// channels of one pixel per accumulator group; v_permlane32_swap pairs the two lane halves' groups into 8 channels and
+// the lane stores 16 bytes.  One barrier per K-step; counted s_waitcnt vmcnt(P (NS-2)) instead of a full drain.
+// Tiles are dealt XCD-aware like xcd_logical_id(): XCD k owns a contiguous range of the (pixel tile, n-tile) sequence.
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void k_gemm1_f16_p(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+                                                                            const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                                            float *__restrict__ out_f32, const ConvF16Args a, const int n_tile_total)
+{
+    constexpr int BK = 64, ROWH = BK, WM = BM / 64, WN = BN / 64, NW = WM * WN;
+    constexpr int AG = BM / 8 / NW, BG = BN / 8 / NW, P = AG + BG;     // LDS-DMA pieces per wavefront and stage
+    constexpr int STAGE = (BM + BN) * ROWH;                            // halves per ring stage
+    static_assert(AG >= 1 && BG >= 1 && NS >= 2 && NS <= 4 && P * (NS - 2) <= 63, "ring shape");
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int HW = a.H * a.W;
+    // this workgroup's tiles: t_first, t_first + S, ... below t_end
+    const int xcd = (int)blockIdx.x & 7, S = (int)gridDim.x >> 3;
+    const int t_first = (int)((long)n_tile_total * xcd / 8) + ((int)blockIdx.x >> 3);
+    const int t_end = (int)((long)n_tile_total * (xcd + 1) / 8);
+    const int my_n = t_first < t_end ? (t_end - t_first + S - 1) / S : 0;
+    if (my_n == 0) return;
+    const int ksteps = a.Cp_in / BK, total = my_n * ksteps;
+
+    const int lrow = lane >> 3, lslot = lane & 7;
+    unsigned a_src[AG], b_src[BG];       // 32-bit byte offsets from wave-uniform bases (tensors below 4 GiB: host check)
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave * BG + i) * 8 + lrow;
+        b_src[i] = (unsigned)(((size_t)row * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8)) * 2);
+    }
+    // ---- producer side: stage (f_i, f_k) = K-step f_k of this workgroup's f_i-th tile
+    int f_i = 0, f_k = 0, f_buf = 0;
+    const char *f_wbase = nullptr;
+    auto fill_tile_setup = [&](int ord) {
+        const int t = t_first + ord * S, pt = t / a.n_tiles, nt = t - pt * a.n_tiles;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const int row = (wave * AG + i) * 8 + lrow;
+            const int q = min(pt * BM + row, a.npix - 1);           // rows past the last pixel re-read it (never stored)
+            a_src[i] = (unsigned)((((size_t)kLead + flat_of_fast(a, q)) * a.Cp_in + (size_t)((lslot ^ ((row >> 1) & 7)) * 8)) * 2);
+        }
+        f_wbase = reinterpret_cast<const char *>(wh + (size_t)nt * BN * a.Cp_in);
+    };
+    auto fill = [&]() {
+        const char *ab = reinterpret_cast<const char *>(act + f_k * BK);
+        const char *bb = f_wbase + (size_t)f_k * BK * 2;
+        _Float16 *As = smem_h + (size_t)f_buf * STAGE, *Bs = As + BM * ROWH;
+#pragma unroll
+        for (int i = 0; i < AG; ++i)
+            lds_dma16(ab, a_src[i], As + (size_t)(wave * AG + i) * 8 * ROWH);
+#pragma unroll
+        for (int i = 0; i < BG; ++i)
+            lds_dma16(bb, b_src[i], Bs + (size_t)(wave * BG + i) * 8 * ROWH);
+        f_buf = f_buf == NS - 1 ? 0 : f_buf + 1;
+        if (++f_k == ksteps) {
+            f_k = 0;
+            if (++f_i < my_n) fill_tile_setup(f_i);
+        }
+    };
+    fill_tile_setup(0);
+    int issued = 0;
+    for (; issued < NS - 1 && issued < total; ++issued) fill();
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    int sg = 0, cur = 0;
+    for (int ti = 0; ti < my_n; ++ti) {
+        const int t = t_first + ti * S, pt = t / a.n_tiles, nt = t - pt * a.n_tiles;
+        const int q0 = pt * BM, n0 = nt * BN;
+        float16_t acc[2][2];             // [pixel 32-tile i][channel 32-tile j]: D rows = channels, columns = pixels
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int k = 0; k < ksteps; ++k, ++sg) {
+            // stage sg has landed once at most the NS-2 younger stages' pieces of this wavefront are outstanding
+            if (issued - sg - 1 >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P * (NS - 2)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();             // ... for every wavefront, and all of them are done reading stage sg-1
+            if (issued < total) { fill(); ++issued; }   // into the buffer stage sg-1 used
+            const _Float16 *As = smem_h + (size_t)cur * STAGE, *Bs = As + BM * ROWH;
+            half8_t af[2][2], bf[2][2];
+            auto read_frags = [&](int kk, int set) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = wm * 64 + u * 32 + frow;
+                    af[set][u] = *reinterpret_cast<const half8_t *>(As + (size_t)row * ROWH + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) * 8));
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int row = wn * 64 + u * 32 + frow;
+                    bf[set][u] = *reinterpret_cast<const half8_t *>(Bs + (size_t)row * ROWH + (((kk * 2 + fhalf) ^ ((row >> 1) & 7)) * 8));
+                }
+            };
+            read_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                if (kk + 1 < BK / 16) read_frags(kk + 1, (kk + 1) & 1);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[kk & 1][j], af[kk & 1][i], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int kk = 0; kk + 1 < BK / 16; ++kk) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            cur = cur == NS - 1 ? 0 : cur + 1;
+        }
+
+        // ---- epilogue straight from the accumulators.  Lane: pixel column lane & 31 of each pixel 32-tile; accumulator
+        // register r of channel 32-tile j = channel j*32 + 8 (r >> 2) + 4 (lane >> 5) + (r & 3).
+        if (out_f32) {                   // the region layer: dense [B][N][H][W] fp32 (32 lanes = 32 consecutive pixels of a channel)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = q0 + wm * 64 + i * 32 + frow;
+                if (q >= a.npix) continue;
+                const int b = (int)fast_div((unsigned)q, a.mHW, a.sHW), rem = q - b * HW;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ch = n0 + wn * 64 + j * 32 + 8 * (r >> 2) + 4 * fhalf + (r & 3);
+                        if (ch >= a.N) continue;
+                        float v = acc[i][j][r] + bias[ch];
+                        if (a.leaky && v < 0.f) v *= 0.1f;
+                        out_f32[((size_t)b * a.N + ch) * HW + rem] = v;
+                    }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = q0 + wm * 64 + i * 32 + frow;
+            const bool qok = q < a.npix;
+            _Float16 *orow = out + ((size_t)kLead + flat_of_fast(a, min(q, a.npix - 1))) * a.Cp_out + a.out_ch_off;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int cb = n0 + wn * 64 + j * 32;
+                unsigned pk[4][2];       // [group g = r >> 2][dword]: this lane's 4 channels 8 g + 4 (lane >> 5) ..+3 as halves
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + cb + 8 * g + 4 * fhalf);
+                    float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                    float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                    if (a.leaky) {
+                        v0 = v0 < 0.f ? v0 * 0.1f : v0; v1 = v1 < 0.f ? v1 * 0.1f : v1;
+                        v2 = v2 < 0.f ? v2 * 0.1f : v2; v3 = v3 < 0.f ? v3 * 0.1f : v3;
+                    }
+                    const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                    pk[g][0] = __builtin_bit_cast(unsigned, h01);
+                    pk[g][1] = __builtin_bit_cast(unsigned, h23);
+                }
+                // lanes 0-31 end up with channels 8 g' .. 8 g' + 7 of group g' = 2 pr, lanes 32-63 with those of 2 pr + 1
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                    const uint2v s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+                    const uint2v s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+                    const int c0 = cb + 8 * (2 * pr + fhalf);
+                    if (qok && c0 < a.n_store) *reinterpret_cast<uint4 *>(orow + c0) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        }
+    }
 }
 
 // Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:

@@ -2064,6 +2064,13 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
     hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
@@ -2539,13 +2546,35 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             const bool glds = bk64 && !getenv("YOLO2_F16_NO_GLDS");   // LDS-DMA staging wherever the K-step is 64
             // Conv layers whose only consumer is the 2x2 pool after them (2 and 6; 10 runs the halo kernel, 16 also
             // feeds the route) store the pooled tensor directly: MFMA rows ordered by pool window, max in the epilogue.
-            const bool fuse_pool = (i == 2 || i == 6) && kNet[i + 1].type == L_MAX && !getenv("YOLO2_F16_NO_POOLFUSE");
+            // (layer 6 only where the persistent halo kernel, which stores the full-resolution tensor, does not take it)
+            // Measured (tools/stamps.py, profiles/r02_f16_halo_wg_timeline.txt): at <= 52x52 the persistent kernel's tile costs what the
+            // one-tile-per-workgroup kernel's does (its epilogue is 6k cycles of VALU work that nothing overlaps either way, and the
+            // next tile's staging slows the taps it runs beside), and its few long workgroups pack worse next to the other lane's
+            // (-4 % at batch 256).  It is used where the halo kernel does not fit: the 104x104 layers (-15..18 % vs k_conv_f16_glds).
+            const bool persist_ok = !getenv("YOLO2_F16_NO_GLDS") && !getenv("YOLO2_F16_NO_HALO") && !getenv("YOLO2_F16_NO_PERSIST") &&
+                                    (l.w > 52 || getenv("YOLO2_F16_PERSIST_ALL"));
+            const bool fuse_pool = (i == 2 || (i == 6 && !persist_ok)) && kNet[i + 1].type == L_MAX && !getenv("YOLO2_F16_NO_POOLFUSE");
             if (fuse_pool) {
                 const auto &tp = c->h_out[i + 1];
                 a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
                 a.Cp_out = tp.Cp;
                 op = tp.d;
                 skip_pool = i + 1;
+            }
+            // 1x1 layers: persistent workgroups over a ring of staged K-steps (k_gemm1_f16_p)
+            if (l.size == 1 && bk64 && (i == 30 || getenv("YOLO2_F16_RING_ALL")) && ((size_t)kLead + (size_t)B * a.PL) * a.Cp_in * 2 < (1ull << 32) && !getenv("YOLO2_F16_NO_RING")) {
+                const int bn = l.n <= 64 ? 64 : 128;
+                a.n_tiles = round_up(l.n, bn) / bn;
+                const int T = ((a.npix + 255) / 256) * a.n_tiles;
+                const int rounds = (T + 255) / 256;                                    // tiles per workgroup
+                const int G = std::min(256, std::max(8, round_up((T + rounds - 1) / rounds, 8)));
+                if (bn == 64)
+                    hipLaunchKernelGGL((k_gemm1_f16_p<256, 64, 3>), dim3(G), dim3(256), 3 * (256 + 64) * 128, st, ip, wp, bp, op, of, a, T);
+                else
+                    hipLaunchKernelGGL((k_gemm1_f16_p<256, 128, 3>), dim3(G), dim3(512), 3 * (256 + 128) * 128, st, ip, wp, bp, op, of, a, T);
+                if (i != 30) cur = &c->h_out[i];
+                ord++;
+                break;
             }
             const int m_tiles = fuse_pool ? (a.npool + 31) / 32 : (a.npix + 127) / 128;   // 128-row tiles (32 pool windows)
             if (l.n <= 64) {
@@ -2558,6 +2587,29 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                 a.n_tiles = round_up(l.n, kBN) / kBN;
                 // 3x3 layers: halo-tile kernel (input tile staged once per 64-channel chunk, nine taps read it
                 // shifted) wherever its LDS arena fits: 2 x lt_rows x 128 B (A) + 3 x 128 x 128 B (B) + fo table
+                // persistent halo-tile kernel: the workgroup walks its tiles, the next tile's staging overlaps this one's tail
+                if (glds && l.size == 3 && l.n % kBN == 0 && persist_ok && !fuse_pool) {
+                    const int lt_rows = round_up(256 + 2 * (l.w + 1), 8) + 8;
+                    const size_t a_bytes = (size_t)2 * lt_rows * 128, cap = 160 * 1024;
+                    const bool off32 = ((size_t)kLead + (size_t)B * a.PL) * std::max(a.Cp_in, a.Cp_out) * 2 < (1ull << 32);
+                    const bool wide = l.n % 256 == 0 && a_bytes + (size_t)2 * 256 * 128 <= cap;
+                    const int bn = wide ? 256 : 128;
+                    const size_t lds = a_bytes + (size_t)2 * bn * 128;
+                    if (off32 && lds <= cap && lt_rows - 8 <= 8 * 8 * 8) {
+                        a.n_tiles = l.n / bn;
+                        const int T = ((a.npix + 255) / 256) * a.n_tiles;
+                        const int rounds = (T + 255) / 256;
+                        const int G = std::min(256, std::max(8, round_up((T + rounds - 1) / rounds, 8)));
+                        const bool m16 = getenv("YOLO2_F16_M16") != nullptr;
+                        if (wide && m16) hipLaunchKernelGGL((k_conv_f16_halo_p<256, 16, 16>), dim3(G), dim3(1024), lds, st, ip, wp, bp, op, a, lt_rows, T);
+                        else if (wide) hipLaunchKernelGGL((k_conv_f16_halo_p<256, 16, 32>), dim3(G), dim3(1024), lds, st, ip, wp, bp, op, a, lt_rows, T);
+                        else if (m16) hipLaunchKernelGGL((k_conv_f16_halo_p<128, 8, 16>), dim3(G), dim3(512), lds, st, ip, wp, bp, op, a, lt_rows, T);
+                        else hipLaunchKernelGGL((k_conv_f16_halo_p<128, 8, 32>), dim3(G), dim3(512), lds, st, ip, wp, bp, op, a, lt_rows, T);
+                        cur = &c->h_out[i];
+                        ord++;
+                        break;
+                    }
+                }
                 if (glds && l.size == 3 && l.n % kBN == 0 && !getenv("YOLO2_F16_NO_HALO")) {
                     // dense tile: 256 pixels + W+1 on either side, rounded to 8-row groups, + 8 zero rows
                     const int lt_rows = round_up(256 + 2 * (l.w + 1), 8) + 8;
@@ -2575,7 +2627,9 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                         if (wide) {
                             a.n_tiles = l.n / 256;
                             const dim3 hgrid(((a.npix + 255) / 256) * a.n_tiles);
-                            if (!getenv("YOLO2_F16_W8"))   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
+                            if (getenv("YOLO2_F16_M16"))
+                                hipLaunchKernelGGL((k_conv_f16_halo<256, 2, 16, 16>), hgrid, dim3(1024), lds256, st, ip, wp, bp, op, a, lt_rows);
+                            else if (!getenv("YOLO2_F16_W8"))   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
                                 hipLaunchKernelGGL((k_conv_f16_halo<256, 2, 16>), hgrid, dim3(1024), lds256, st, ip, wp, bp, op, a, lt_rows);
                             else
                                 hipLaunchKernelGGL((k_conv_f16_halo<256, 2>), hgrid, dim3(512), lds256, st, ip, wp, bp, op, a, lt_rows);
