@@ -251,7 +251,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
     ctx.close()
 
 
-def sub_fp16_b256(model, dev, steps=5, warmup=2):
+def sub_fp16_b256(model, dev, steps=10, warmup=3):
     """configs[3] under the driver's clock: YOLOv2 fp16 at batch 256 on the MFMA path, as a sub-record of the default line."""
     B = 256
     ctx = hipdrv.Yolo2Hip(dev.index or 0)

@@ -2453,12 +2453,15 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     hipStream_t st = (hipStream_t)stream;
     // Two half-batch lanes like the int16 path: the big-tile kernels run one workgroup per CU and a layer is only
     // 2-3 generations of workgroups, so a second stream's launches fill the last, partly empty generation.
-    if (!c->is_lane && batch >= 64 && batch % 2 == 0 && !getenv("YOLO2_F16_NO_LANES")) {
-        if (c->f16_lanes.empty()) {
+    const int want_lanes = getenv("YOLO2_F16_LANES") ? std::max(1, std::min(8, atoi(getenv("YOLO2_F16_LANES")))) : 2;
+    if (!c->is_lane && batch >= 64 && want_lanes > 1 && batch % want_lanes == 0 && !getenv("YOLO2_F16_NO_LANES")) {
+        if ((int)c->f16_lanes.size() != want_lanes) {
+            for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);
+            c->f16_lanes.clear();
             if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
             std::vector<yolo2_hip_ctx *> made;   // committed only when both lanes are complete
             bool ok = true;
-            for (int i = 0; i < 2 && ok; ++i) {
+            for (int i = 0; i < want_lanes && ok; ++i) {
                 yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
                 if (!l) { ok = false; break; }
                 made.push_back(l);
@@ -2478,9 +2481,9 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             c->f16_lanes = made;
             if (c->prof) (void)yolo2_hip_set_profiling(c->f16_lanes[0], 1);
         }
-        const int half = batch / 2;
+        const int half = batch / want_lanes;
         HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < want_lanes; ++i) {
             yolo2_hip_ctx *l = c->f16_lanes[i];
             HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
             const int rc = yolo2_hip_run_batch_fp16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
@@ -2599,6 +2602,8 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                         a.n_tiles = l.n / bn;
                         const int T = ((a.npix + 255) / 256) * a.n_tiles;
                         const int rounds = (T + 255) / 256;
+                        // (Launched with one tile per workgroup - the same kernel, only the LDS-free epilogue and the operand order
+                        //  differ from k_conv_f16_halo - it measured 2.8 % slower over the pass at batch 256.)
                         const int G = std::min(256, std::max(8, round_up((T + rounds - 1) / rounds, 8)));
                         const bool m16 = getenv("YOLO2_F16_M16") != nullptr;
                         if (wide && m16) hipLaunchKernelGGL((k_conv_f16_halo_p<256, 16, 16>), dim3(G), dim3(1024), lds, st, ip, wp, bp, op, a, lt_rows, T);
