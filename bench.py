@@ -114,12 +114,16 @@ def cpu_baseline(model, frames, gpu_regions):
     return out
 
 
+INT16_DEVICE_SOURCES = ("kernels_int16.hpp", "kernels_pre.hpp", "layout.hpp")
+
+
 def kernel_source_hash():
-    """sha256 over the kernel sources: ties a committed PMC measurement to the build it was taken from."""
+    """sha256 over the device sources of the int16 path (kernels, input packing, layouts): ties the committed PMC traffic
+    measurement of that path to the kernels it was taken from (the fp16 / fp32 kernel files do not enter)."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc")
-    for f in sorted(os.listdir(d)):
+    for f in INT16_DEVICE_SOURCES:
         h.update(f.encode())
         h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

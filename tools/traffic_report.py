@@ -63,13 +63,9 @@ except (IndexError, KeyError):
     pass
 for k, e in res.items():
     e["hbm_bytes_per_launch"] = 2.0 * e.get("FETCH_SIZE_KB_per_launch", 0.0) * 1024 + e.get("WRITE_SIZE_KB_per_launch", 0.0) * 1024
-import hashlib
-h = hashlib.sha256()
-d = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc")
-for f in sorted(os.listdir(d)):
-    h.update(f.encode())
-    h.update(open(os.path.join(d, f), "rb").read())
-doc = {"batch": batch, "kernel_source_hash": h.hexdigest()[:16], "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, (steps=6 - steps=2)/4; "
+sys.path.insert(0, ROOT)
+import bench   # the hash of the int16 device sources, one definition
+doc = {"batch": batch, "kernel_source_hash": bench.kernel_source_hash(), "hashed_sources": list(bench.INT16_DEVICE_SOURCES), "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, separate passes, (steps=6 - steps=2)/4; "
                                    "bytes = 2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B) + WRITE_SIZE, KB = 1024 B",
        "calibration_on_k_maxpool2": cal, "kernels": res}
 try:

@@ -1250,6 +1250,140 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void k_gemm1_f16_p(cons
     }
 }
 
+// ---- the 32-channel 3x3 layer (layer 2: 208x208, 32 -> 64, K = 288) + its 2x2 pool ---------------------
+// With 32-channel items a K-step of one tap is two MFMA k-slices: in the per-tap kernels above this layer is one
+// barrier per 4 MFMAs and runs at 0.5 PF.  Here nothing is staged per tap: one workgroup owns a 16 x 16 tile of conv
+// outputs x all 64 channels; its 18 x 18 input patch (324 rows of 64 B; pixels outside the image are the layout's
+// zero pad items, no masking) and ALL nine taps' weights (9 x 64 rows of 64 B = 36 KB) go into LDS once by LDS-DMA,
+// then four wavefronts (four tile rows each) run 72 MFMAs apiece with no barrier in between.  57 KB of LDS: two
+// workgroups per CU, one stages or stores while the other multiplies.
+// LDS rows are 64 B, four to a bank row: a ds_read_b128 lane group is conflict-free when its 16 rows are distinct
+// mod 16 (slot = chunk ^ ((row >> 2) & 3)).  A 32-row MFMA block is two tile rows (patch rows 18 apart): its second
+// half is rotated - MFMA row 16 + j = pixel (j - 2) mod 16 of the lower tile row - which makes both hardware lane
+// groups {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} cover all 16 residues for every tap shift.
+// Operands swapped as in k_gemm1_f16_p (D rows = channels): a lane leaves with 4 consecutive channels of a pixel per
+// accumulator group, written as 8-byte pieces into a [pixel][channel] tile in LDS (over the dead patch / weights); the
+// 2x2 pool is a max over four rows of that tile (same bits as store_pooled: bias + leaky + fp16 rounding are
+// monotonic), stored in 16-byte pieces.  K order tap-major like k_conv_f16: the same bits as that kernel.
+__global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
+                                                          const float *__restrict__ bias, _Float16 *__restrict__ out,
+                                                          const ConvF16Args a)
+{
+    constexpr int TS = 16, PW = TS + 2, PROWS = 336;            // patch pitch (pixels), LDS rows reserved for the patch (21 DMA pieces of 16 rows)
+    constexpr int ROWB = 64;                                    // bytes per LDS row (32 halves)
+    constexpr int kWRows = 9 * 64, kCtPitch = 144;              // weight rows; bytes per pixel row of the epilogue tile (64 ch + pad)
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    char *lds = reinterpret_cast<char *>(smem_h);
+    char *Wl = lds;                                             // [9 * 64][64 B]
+    char *Pl = lds + kWRows * ROWB;                             // [336][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = a.W / TS, tiles_y = a.H / TS;
+    const int b = (int)blockIdx.x / (tiles_x * tiles_y), tr = (int)blockIdx.x % (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * TS, tx0 = (tr % tiles_x) * TS;
+
+    // ---- stage weights (36 pieces) and patch (21 pieces): piece p covers LDS rows 16 p .. 16 p + 15, lane = (row, slot)
+    {
+        const int lr = lane >> 2, slot = lane & 3;
+        const char *wb = reinterpret_cast<const char *>(wh);
+        for (int p = wave; p < 36; p += 4) {
+            const int row = p * 16 + lr, tap = row >> 6, n = row & 63;
+            const unsigned src = (unsigned)(((n * 9 + tap) * 32 + ((slot ^ ((row >> 2) & 3)) * 8)) * 2);
+            lds_dma16(wb, src, reinterpret_cast<_Float16 *>(Wl + p * 1024));
+        }
+        // item of patch pixel (py, px): b PL + (ty0 + py) Wp + tx0 - 1 + px   (pixel (ty0 - 1 + py, tx0 - 1 + px))
+        const char *ab = reinterpret_cast<const char *>(act + ((size_t)kLead + (size_t)b * a.PL + (size_t)ty0 * a.Wp + tx0 - 1) * 32);
+        for (int p = wave; p < 21; p += 4) {
+            const int row = min(p * 16 + lr, PW * PW - 1), py = row / PW, px = row - py * PW;
+            const unsigned src = (unsigned)(((py * a.Wp + px) * 32 + ((slot ^ (((p * 16 + lr) >> 2) & 3)) * 8)) * 2);
+            lds_dma16(ab, src, reinterpret_cast<_Float16 *>(Pl + p * 1024));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- this lane's fragment rows
+    const int c = lane & 31, h = lane >> 5;
+    const int pxl = c < 16 ? c : ((c - 18) & 15);               // pixel column of MFMA row c inside its tile row
+    int arow[2];                                                // patch row of the centre tap, pixel block i = tile rows (4 wave + 2 i, +1)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) arow[i] = (4 * wave + 2 * i + (c >> 4) + 1) * PW + pxl + 1;
+    const int bkey = (c >> 2) & 3;                              // weight row = tap * 64 + j * 32 + c: its swizzle key depends on c only
+    int boff[2];                                                // byte offset of this lane's weight fragment, k-slice 0 / 1, at tap 0, j 0
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) boff[kk] = c * ROWB + (((kk * 2 + h) ^ bkey) * 16);
+
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    half8_t af[2][2], bf[2][2];
+    auto read_frags = [&](int tap, int kk, int set) {
+        const int toff = (tap / 3 - 1) * PW + (tap % 3 - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int R = arow[i] + toff;
+            af[set][i] = *reinterpret_cast<const half8_t *>(Pl + R * ROWB + (((kk * 2 + h) ^ ((R >> 2) & 3)) * 16));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bf[set][j] = *reinterpret_cast<const half8_t *>(Wl + tap * (64 * ROWB) + j * (32 * ROWB) + boff[kk]);
+    };
+    read_frags(0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {                              // slice s = (tap s / 2, k-slice s % 2); the next slice's fragments are read ahead
+        if (s + 1 < 18) read_frags((s + 1) >> 1, (s + 1) & 1, (s + 1) & 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[s & 1][j], af[s & 1][i], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();                                            // every wavefront is done with the patch and the weights
+
+    // ---- epilogue: bias + leaky + fp16, [pixel][channel] tile in LDS (8-byte pieces), 2x2 max, 16-byte stores
+    char *Ct = lds;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int pix = (4 * wave + 2 * i + (c >> 4)) * TS + pxl;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                       // register r = channel j * 32 + 8 (r >> 2) + 4 h + (r & 3)
+                const int ch = j * 32 + 8 * g + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias + ch);
+                float v0 = acc[i][j][4 * g + 0] + bv.x, v1 = acc[i][j][4 * g + 1] + bv.y;
+                float v2 = acc[i][j][4 * g + 2] + bv.z, v3 = acc[i][j][4 * g + 3] + bv.w;
+                if (a.leaky) {
+                    v0 = v0 < 0.f ? v0 * 0.1f : v0; v1 = v1 < 0.f ? v1 * 0.1f : v1;
+                    v2 = v2 < 0.f ? v2 * 0.1f : v2; v3 = v3 < 0.f ? v3 * 0.1f : v3;
+                }
+                const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                *reinterpret_cast<uint2 *>(Ct + pix * kCtPitch + ch * 2) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+            }
+    }
+    __syncthreads();
+    {   // 64 pooled pixels x 4 pieces of 16 channels: one per thread
+        const int pp = tid >> 2, ck = tid & 3, py = pp >> 3, px = pp & 7;
+        half8_t m[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const char *p00 = Ct + ((2 * py) * TS + 2 * px) * kCtPitch + ck * 32 + q * 16;
+            half8_t v = *reinterpret_cast<const half8_t *>(p00);
+            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + kCtPitch));
+            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + TS * kCtPitch));
+            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + (TS + 1) * kCtPitch));
+            m[q] = v;
+        }
+        const int oy = ty0 / 2 + py, ox = tx0 / 2 + px;
+        _Float16 *o = out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + ox) * a.Cp_out + a.out_ch_off + ck * 16;
+        *reinterpret_cast<half8_t *>(o) = m[0];
+        *reinterpret_cast<half8_t *>(o + 8) = m[1];
+    }
+}
+
 // Layer 0 + layer 1 fused (conv 3->32 3x3 + leaky + 2x2 max pool) straight from the float frames:
 // K = 27 is too thin for the matrix cores, and the 416x416x32 intermediate is never needed again
 // (yolov2.cfg: layer 1 is its only consumer), so this kernel keeps it in registers.  One lane owns

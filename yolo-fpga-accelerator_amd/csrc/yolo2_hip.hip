@@ -2554,9 +2554,12 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             // one-tile-per-workgroup kernel's does (its epilogue is 6k cycles of VALU work that nothing overlaps either way, and the
             // next tile's staging slows the taps it runs beside), and its few long workgroups pack worse next to the other lane's
             // (-4 % at batch 256).  It is used where the halo kernel does not fit: the 104x104 layers (-15..18 % vs k_conv_f16_glds).
+            // Layer 6 stays on the pool-fused per-tap kernel: the persistent kernel stores the full-resolution tensor, and the pool
+            // kernel that then has to follow (0.08 ms at batch 128) costs more than the conv gains (0.31 -> 0.26 ms).
+            const bool pool_next = kNet[i + 1].type == L_MAX && !getenv("YOLO2_F16_NO_POOLFUSE");
             const bool persist_ok = !getenv("YOLO2_F16_NO_GLDS") && !getenv("YOLO2_F16_NO_HALO") && !getenv("YOLO2_F16_NO_PERSIST") &&
-                                    (l.w > 52 || getenv("YOLO2_F16_PERSIST_ALL"));
-            const bool fuse_pool = (i == 2 || (i == 6 && !persist_ok)) && kNet[i + 1].type == L_MAX && !getenv("YOLO2_F16_NO_POOLFUSE");
+                                    ((l.w > 52 && !(i == 6 && pool_next)) || getenv("YOLO2_F16_PERSIST_ALL"));
+            const bool fuse_pool = (i == 2 || (i == 6 && !persist_ok)) && pool_next;
             if (fuse_pool) {
                 const auto &tp = c->h_out[i + 1];
                 a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
@@ -2576,6 +2579,15 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
                 else
                     hipLaunchKernelGGL((k_gemm1_f16_p<256, 128, 3>), dim3(G), dim3(512), 3 * (256 + 128) * 128, st, ip, wp, bp, op, of, a, T);
                 if (i != 30) cur = &c->h_out[i];
+                ord++;
+                break;
+            }
+            // the 32-channel layer + its pool: 16 x 16 tiles, patch and all nine taps' weights resident in LDS (k_conv_f16_c32_pool)
+            if (fuse_pool && a.Cp_in == 32 && l.size == 3 && l.n == 64 && l.h % 16 == 0 && l.w % 16 == 0 && a.Cp_out >= 64 &&
+                ((size_t)kLead + (size_t)B * a.PL) * 64 < (1ull << 32) && !getenv("YOLO2_F16_NO_C32")) {
+                set_fast_div(a);
+                hipLaunchKernelGGL(k_conv_f16_c32_pool, dim3((unsigned)B * (l.h / 16) * (l.w / 16)), dim3(256), (9 * 64 + 336) * 64, st, ip, wp, bp, op, a);
+                cur = &c->h_out[i + 1];
                 ord++;
                 break;
             }
