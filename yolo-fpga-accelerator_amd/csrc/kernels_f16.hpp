@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / 64) * 64) void k_gemm1_f16_p(cons
 // monotonic), stored in 16-byte pieces.  K order tap-major like k_conv_f16: the same bits as that kernel.
 __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                           const float *__restrict__ bias, _Float16 *__restrict__ out,
-                                                          const ConvF16Args a)
+                                                          const ConvF16Args a, const int n_tile_total)
 {
     constexpr int TS = 16, PW = TS + 2, PROWS = 336;            // patch pitch (pixels), LDS rows reserved for the patch (21 DMA pieces of 16 rows)
     constexpr int ROWB = 64;                                    // bytes per LDS row (32 halves)
@@ -1278,29 +1278,18 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
     char *Pl = lds + kWRows * ROWB;                             // [336][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_x = a.W / TS, tiles_y = a.H / TS;
-    const int b = (int)blockIdx.x / (tiles_x * tiles_y), tr = (int)blockIdx.x % (tiles_x * tiles_y);
-    const int ty0 = (tr / tiles_x) * TS, tx0 = (tr % tiles_x) * TS;
 
-    // ---- stage weights (36 pieces) and patch (21 pieces): piece p covers LDS rows 16 p .. 16 p + 15, lane = (row, slot)
+    // ---- the weights are staged ONCE per workgroup (36 pieces: piece p covers LDS rows 16 p .. 16 p + 15, lane = (row, slot));
+    // the workgroup then walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...
+    const int lr = lane >> 2, slot = lane & 3;
     {
-        const int lr = lane >> 2, slot = lane & 3;
         const char *wb = reinterpret_cast<const char *>(wh);
         for (int p = wave; p < 36; p += 4) {
             const int row = p * 16 + lr, tap = row >> 6, n = row & 63;
             const unsigned src = (unsigned)(((n * 9 + tap) * 32 + ((slot ^ ((row >> 2) & 3)) * 8)) * 2);
             lds_dma16(wb, src, reinterpret_cast<_Float16 *>(Wl + p * 1024));
         }
-        // item of patch pixel (py, px): b PL + (ty0 + py) Wp + tx0 - 1 + px   (pixel (ty0 - 1 + py, tx0 - 1 + px))
-        const char *ab = reinterpret_cast<const char *>(act + ((size_t)kLead + (size_t)b * a.PL + (size_t)ty0 * a.Wp + tx0 - 1) * 32);
-        for (int p = wave; p < 21; p += 4) {
-            const int row = min(p * 16 + lr, PW * PW - 1), py = row / PW, px = row - py * PW;
-            const unsigned src = (unsigned)(((py * a.Wp + px) * 32 + ((slot ^ (((p * 16 + lr) >> 2) & 3)) * 8)) * 2);
-            lds_dma16(ab, src, reinterpret_cast<_Float16 *>(Pl + p * 1024));
-        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     // ---- this lane's fragment rows
     const int c = lane & 31, h = lane >> 5;
     const int pxl = c < 16 ? c : ((c - 18) & 15);               // pixel column of MFMA row c inside its tile row
@@ -1312,6 +1301,19 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) boff[kk] = c * ROWB + (((kk * 2 + h) ^ bkey) * 16);
 
+    for (int tile = (int)blockIdx.x; tile < n_tile_total; tile += (int)gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+    const int ty0 = (tr / tiles_x) * TS, tx0 = (tr % tiles_x) * TS;
+    {   // stage the patch (21 pieces); item of patch pixel (py, px): b PL + (ty0 + py) Wp + tx0 - 1 + px   (pixel (ty0 - 1 + py, tx0 - 1 + px))
+        const char *ab = reinterpret_cast<const char *>(act + ((size_t)kLead + (size_t)b * a.PL + (size_t)ty0 * a.Wp + tx0 - 1) * 32);
+        for (int p = wave; p < 21; p += 4) {
+            const int row = min(p * 16 + lr, PW * PW - 1), py = row / PW, px = row - py * PW;
+            const unsigned src = (unsigned)(((py * a.Wp + px) * 32 + ((slot ^ (((p * 16 + lr) >> 2) & 3)) * 8)) * 2);
+            lds_dma16(ab, src, reinterpret_cast<_Float16 *>(Pl + p * 1024));
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     float16_t acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -1343,11 +1345,14 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
     }
     __syncthreads();                                            // every wavefront is done with the patch and the weights
 
-    // ---- epilogue: bias + leaky + fp16, [pixel][channel] tile in LDS (8-byte pieces), 2x2 max, 16-byte stores
-    char *Ct = lds;
+    // ---- epilogue: bias + leaky + fp16; the horizontal half of the 2x2 pool is a max with the neighbouring lane (MFMA
+    // columns 2p, 2p + 1 are the pixels 2p, 2p + 1 of one tile row in both halves of a block), the even lanes write
+    // [tile row][pooled column][channel] into LDS over the dead patch (8-byte pieces), the vertical half is a max over
+    // two rows of that tile; 16-byte stores.  Same bits as store_pooled: bias + leaky + fp16 rounding are monotonic.
+    char *Ct = Pl;                                              // [16][8][kCtPitch]: 18 KB of the patch's 21 KB
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int pix = (4 * wave + 2 * i + (c >> 4)) * TS + pxl;
+        const int prow = (4 * wave + 2 * i + (c >> 4)) * 8 + (pxl >> 1);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -1360,8 +1365,13 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
                     v0 = v0 < 0.f ? v0 * 0.1f : v0; v1 = v1 < 0.f ? v1 * 0.1f : v1;
                     v2 = v2 < 0.f ? v2 * 0.1f : v2; v3 = v3 < 0.f ? v3 * 0.1f : v3;
                 }
-                const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
-                *reinterpret_cast<uint2 *>(Ct + pix * kCtPitch + ch * 2) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                const unsigned n01 = (unsigned)__builtin_amdgcn_mov_dpp((int)__builtin_bit_cast(unsigned, h01), 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                const unsigned n23 = (unsigned)__builtin_amdgcn_mov_dpp((int)__builtin_bit_cast(unsigned, h23), 0xB1, 0xF, 0xF, true);
+                h01 = __builtin_elementwise_max(h01, __builtin_bit_cast(half2_t, n01));
+                h23 = __builtin_elementwise_max(h23, __builtin_bit_cast(half2_t, n23));
+                if (!(c & 1))
+                    *reinterpret_cast<uint2 *>(Ct + prow * kCtPitch + ch * 2) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
             }
     }
     __syncthreads();
@@ -1370,17 +1380,15 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
         half8_t m[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const char *p00 = Ct + ((2 * py) * TS + 2 * px) * kCtPitch + ck * 32 + q * 16;
-            half8_t v = *reinterpret_cast<const half8_t *>(p00);
-            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + kCtPitch));
-            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + TS * kCtPitch));
-            v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(p00 + (TS + 1) * kCtPitch));
-            m[q] = v;
+            const char *p00 = Ct + ((2 * py) * 8 + px) * kCtPitch + ck * 32 + q * 16;
+            m[q] = __builtin_elementwise_max(*reinterpret_cast<const half8_t *>(p00), *reinterpret_cast<const half8_t *>(p00 + 8 * kCtPitch));
         }
         const int oy = ty0 / 2 + py, ox = tx0 / 2 + px;
         _Float16 *o = out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + ox) * a.Cp_out + a.out_ch_off + ck * 16;
         *reinterpret_cast<half8_t *>(o) = m[0];
         *reinterpret_cast<half8_t *>(o + 8) = m[1];
+    }
+    __syncthreads();                                            // the pooled tile is read before the next patch lands on it
     }
 }
 

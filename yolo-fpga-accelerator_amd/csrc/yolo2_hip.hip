@@ -2586,7 +2586,8 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             if (fuse_pool && a.Cp_in == 32 && l.size == 3 && l.n == 64 && l.h % 16 == 0 && l.w % 16 == 0 && a.Cp_out >= 64 &&
                 ((size_t)kLead + (size_t)B * a.PL) * 64 < (1ull << 32) && !getenv("YOLO2_F16_NO_C32")) {
                 set_fast_div(a);
-                hipLaunchKernelGGL(k_conv_f16_c32_pool, dim3((unsigned)B * (l.h / 16) * (l.w / 16)), dim3(256), (9 * 64 + 336) * 64, st, ip, wp, bp, op, a);
+                const int T = B * (l.h / 16) * (l.w / 16);
+                hipLaunchKernelGGL(k_conv_f16_c32_pool, dim3((unsigned)std::min(T, 512)), dim3(256), (9 * 64 + 336) * 64, st, ip, wp, bp, op, a, T);   // two workgroups per CU, weights staged once each
                 cur = &c->h_out[i + 1];
                 ord++;
                 break;
