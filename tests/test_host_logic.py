@@ -148,3 +148,42 @@ def test_shard_range_rejects_bad_arguments_and_multi_needs_a_gpu():
     assert L.yolo2_hip_multi_create(devs, 2, ctypes.byref(m)) == hipdrv.YOLO2_INIT_ERROR     # loud, no CPU fallback
     assert b"no HIP device" in L.yolo2_hip_last_error()
     assert L.dma_buffer_init() == -1
+
+
+def test_committed_traffic_measurement_belongs_to_the_int16_kernels_in_the_tree():
+    """`roofline.traffic` is read from a committed PMC measurement (tools/traffic.sh); bench.py only reports it when the file's
+    hash equals the hash of the int16 device sources.  This keeps the two together: a kernel change without a new measurement
+    fails here instead of silently turning the bench field into null."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    doc = json.load(open(os.path.join(root, bench.TRAFFIC_FILE)))
+    assert doc["kernel_source_hash"] == bench.kernel_source_hash(), "int16 kernels changed: re-run tools/traffic.sh and commit its JSON"
+    assert doc["hashed_sources"] == list(bench.INT16_DEVICE_SOURCES)
+    fam = doc["kernels"]["y2::k_conv_i16<KS=3,...>"]
+    assert fam["launches_per_step"] % 3 == 0 and fam["hbm_bytes_per_launch"] > 0
+
+
+def test_fast_div_magic_is_exact_for_the_layer_geometries():
+    """The multiply-high division of the fp16 kernels' prologues (kernels_f16.hpp::fast_div_magic / fast_div, Granlund-Montgomery
+    round-up form), restated: exact for every numerator a lane can form, for every H*W and W of the network."""
+    def magic(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        return ((((1 << l) - d) << 32) // d + 1) & 0xFFFFFFFF, l - 1
+
+    def fdiv(n, m, s):
+        t = (m * n) >> 32
+        return ((t + ((n - t) >> 1)) & 0xFFFFFFFF) >> s
+
+    rng = np.random.default_rng(5)
+    for d in sorted({l.w for l in net.CONVS} | {l.h * l.w for l in net.CONVS}):
+        m, s = magic(d)
+        ns = np.concatenate([np.arange(0, 4 * d + 2), rng.integers(0, 2 ** 32, 20000), np.array([2 ** 32 - 1, 2 ** 31, 2 ** 31 - 1])])
+        for k in (1, 7, 4096 * 169, 2 ** 32 // d - 1):
+            ns = np.concatenate([ns, np.array([k * d - 1, k * d, k * d + 1])])
+        for n in ns.tolist():
+            n &= 0xFFFFFFFF
+            assert fdiv(n, m, s) == n // d, (d, n)
