@@ -57,23 +57,10 @@ struct ConvF16Args {
     int stamp;             // diagnostic builds (-DY2_STAMPS): this launch records its workgroups' timeline in y2_stamps
 };
 
-// Granlund-Montgomery round-up division: exact for every 32-bit numerator, divisor >= 2
-inline void fast_div_magic(unsigned d, unsigned &m, unsigned &s)
-{
-    unsigned l = 0;
-    while ((1ull << l) < d) ++l;
-    m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
-    s = l - 1;
-}
 inline void set_fast_div(ConvF16Args &a)
 {
     fast_div_magic((unsigned)(a.H * a.W), a.mHW, a.sHW);
     fast_div_magic((unsigned)a.W, a.mW, a.sW);
-}
-__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s)
-{
-    const unsigned t = __umulhi(m, n);
-    return (t + ((n - t) >> 1)) >> s;
 }
 // (b, y, x) of pixel index q
 __device__ __forceinline__ void pixel_of(const ConvF16Args &a, int q, int &b, int &y, int &x)
@@ -1269,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
                                                           const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                           const ConvF16Args a, const int n_tile_total)
 {
-    constexpr int TS = 16, PW = TS + 2, PROWS = 336;            // patch pitch (pixels), LDS rows reserved for the patch (21 DMA pieces of 16 rows)
+    constexpr int TS = 16, PW = TS + 2;                         // tile side, patch pitch (pixels); the patch is staged as 21 DMA pieces of 16 rows = 336 LDS rows
     constexpr int ROWB = 64;                                    // bytes per LDS row (32 halves)
     constexpr int kWRows = 9 * 64, kCtPitch = 144;              // weight rows; bytes per pixel row of the epilogue tile (64 ch + pad)
     extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];

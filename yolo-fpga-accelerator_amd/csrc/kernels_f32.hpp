@@ -53,10 +53,9 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float4 *__restrict__ in,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int tile = blockIdx.x, mb = blockIdx.y;
     if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, mb);
-    const int HW = a.H * a.W;
     const int q0 = tile * T, qlast = min(q0 + T, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
-    const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
+    const int fmin = flat_of(a, q0), fmax = flat_of(a, qlast);
     const int tile_start = fmin - halo;
     const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
     const int buf_items = a.lt_max + WIT;          // one LDS buffer: input tile, then the group's 32-channel weight slice
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void k_conv_f32(const float4 *__restrict__ in,
     for (int p = 0; p < P; ++p) {
         const int q = q0 + p * 64 + lane;
         valid[p] = q <= qlast;
-        fo[p] = flat_of(min(q, qlast), HW, a.W, a.Wp, a.PL);
+        fo[p] = flat_of(a, min(q, qlast));
         const int lo = fo[p] - tile_start;
 #pragma unroll
         for (int i = 0; i < KS; ++i) rowaddr[p][i] = (KS == 3) ? (lo + (i - 1) * a.Wp - 1) * 16 : lo * 16;

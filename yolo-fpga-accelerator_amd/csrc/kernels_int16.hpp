@@ -48,7 +48,19 @@ struct ConvArgs {
     int oWp, oPL;              // row pitch / plane size of the pooled tensor (items)
     long pool_cg_stride;       // items between channel groups of the pooled tensor
     long pool_base;            // item offset of its channel group 0, incl. lead
+    // division by H*W, W (and, fused pool, by (H/2)*(W/2), W/2) as multiply-high + shift: layout.hpp fast_div, set by set_conv_div
+    unsigned mHW, sHW, mW, sW, mOHW, sOHW, mOW, sOW;
 };
+
+inline void set_conv_div(ConvArgs &a)
+{
+    auto one = [](unsigned d, unsigned &m, unsigned &s) { if (d < 2) { m = 0; s = 32; } else fast_div_magic(d, m, s); };   // s = 32: divisor 1
+    one((unsigned)(a.H * a.W), a.mHW, a.sHW);
+    one((unsigned)a.W, a.mW, a.sW);
+    one((unsigned)((a.H / 2) * (a.W / 2)), a.mOHW, a.sOHW);
+    one((unsigned)(a.W / 2), a.mOW, a.sOW);
+}
+__device__ __forceinline__ int div_c(int n, unsigned m, unsigned s) { return s >= 32 ? n : (int)fast_div((unsigned)n, m, s); }
 
 // core_compute.cpp:191-197: x<0 ? x/10 (C division, toward zero) : x.  For u in [1,32768]
 // floor(u/10) == (u*52429)>>19 (checked exhaustively in tests/test_host_logic.py).
@@ -195,13 +207,13 @@ __device__ __forceinline__ long step64(long acc, int2 x, int2 w, const ConvArgs 
 }
 
 // Pixel index q (raster over b, y, x of real pixels) -> flat item offset inside a channel group.
-__device__ __forceinline__ int flat_of(int q, int HW, int W, int Wp, int PL)
+__device__ __forceinline__ int flat_of(const ConvArgs &a, int q)
 {
-    const int b = q / HW;
-    const int r = q - b * HW;
-    const int y = r / W;
-    const int x = r - y * W;
-    return b * PL + (y + 1) * Wp + x;
+    const int b = div_c(q, a.mHW, a.sHW);
+    const int r = q - b * (a.H * a.W);
+    const int y = div_c(r, a.mW, a.sW);
+    const int x = r - y * a.W;
+    return b * a.PL + (y + 1) * a.Wp + x;
 }
 
 // Conv KSxKS, stride 1, 'same' padding, on the item layout.
@@ -270,12 +282,11 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     int tile = blockIdx.x, yb = blockIdx.y;
     if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
     const int mb = a.mb_list ? a.mb_list[yb] : yb;
-    const int HW = a.H * a.W;
     const int q0 = tile * T;
     const int qlast = min(q0 + T, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
-    const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL);
-    const int fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
+    const int fmin = flat_of(a, q0);
+    const int fmax = flat_of(a, qlast);
     const int tile_start = fmin - halo;
     const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
 
@@ -286,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     for (int p = 0; p < P; ++p) {
         const int q = q0 + p * 64 + lane;
         valid[p] = q <= qlast;
-        fo[p] = flat_of(min(q, qlast), HW, a.W, a.Wp, a.PL);
+        fo[p] = flat_of(a, min(q, qlast));
         const int lo = fo[p] - tile_start;
 #pragma unroll
         for (int i = 0; i < KS; ++i)
@@ -495,9 +506,9 @@ __global__ __launch_bounds__(256) void k_conv_i16_pool(const int2 *__restrict__ 
     const int OW = a.W >> 1, OHW = (a.H >> 1) * OW;
     // flat item offset of the top-left pixel of window wq
     auto win_tl = [&](int wq, int &b, int &oy, int &ox) -> int {
-        b = wq / OHW;
+        b = div_c(wq, a.mOHW, a.sOHW);
         const int r = wq - b * OHW;
-        oy = r / OW;
+        oy = div_c(r, a.mOW, a.sOW);
         ox = r - oy * OW;
         return b * a.PL + (2 * oy + 1) * a.Wp + 2 * ox;
     };
@@ -672,11 +683,10 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     int tile = blockIdx.x, yb = blockIdx.y;
     if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
     const int mb = a.mb_list ? a.mb_list[yb] : yb;
-    const int HW = a.H * a.W;
     const int q0 = tile * TT;
     const int qlast = min(q0 + TT, a.npix) - 1;
     const int halo = (KS == 3) ? a.Wp + 1 : 0;
-    const int fmin = flat_of(q0, HW, a.W, a.Wp, a.PL), fmax = flat_of(qlast, HW, a.W, a.Wp, a.PL);
+    const int fmin = flat_of(a, q0), fmax = flat_of(a, qlast);
     const int tile_start = fmin - halo;
     const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
     const int Q = a.CGin / S;                               // channel groups per split
@@ -688,7 +698,7 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
     for (int p = 0; p < PP; ++p) {
         const int qp = q0 + pix + p * T;
         valid[p] = (qp <= qlast) && split == 0;             // split-0 lanes hold the combined result
-        fo[p] = flat_of(min(qp, qlast), HW, a.W, a.Wp, a.PL);
+        fo[p] = flat_of(a, min(qp, qlast));
         const int lo = fo[p] - tile_start;
 #pragma unroll
         for (int i = 0; i < KS; ++i) rowaddr[p][i] = (split * a.lt_max + ((KS == 3) ? (lo + (i - 1) * a.Wp - 1) : lo)) * 8;

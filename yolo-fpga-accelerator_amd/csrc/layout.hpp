@@ -62,4 +62,23 @@ inline int tile_items_bound(const ActGeom &g, int T, int halo)
     return T + rows + frames * g.Wp + 2 * halo + 1;
 }
 
+// Division by a launch constant as multiply-high + shift.  The generic 32-bit division the compiler emits is ~30 VALU
+// instructions; a conv workgroup's prologue needs 6-14 of them (pixel index -> frame / row / column), which for the layers with
+// few input channels is a fifth of the workgroup's life.
+// Granlund-Montgomery round-up division: exact for every 32-bit numerator, divisor >= 2
+inline void fast_div_magic(unsigned d, unsigned &m, unsigned &s)
+{
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    m = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+    s = l - 1;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned fast_div(unsigned n, unsigned m, unsigned s)
+{
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> 1)) >> s;
+}
+#endif
+
 }  // namespace y2

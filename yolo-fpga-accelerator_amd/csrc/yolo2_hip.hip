@@ -208,6 +208,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.CGin = gin.CG;
     a.CGout = CGout;
     a.npix = npix;
+    set_conv_div(a);
     a.in_cg_stride = gin.cg_stride;
     a.out_cg_stride = out_cg_stride;
     a.out_base = out_base;
@@ -2229,6 +2230,7 @@ static void plan_conv_f32(ConvPlan &p, const LayerDesc &l, const ActGeom &gin, l
     a.CGin = gin.CG;
     a.CGout = (l.n + 3) / 4;
     a.npix = gin.B * gin.H * gin.W;
+    set_conv_div(a);
     a.in_cg_stride = gin.cg_stride;
     a.out_cg_stride = out_cg_stride;
     a.out_base = out_base;
