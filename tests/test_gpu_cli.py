@@ -86,6 +86,16 @@ def test_cli_fp32_matches_reference_fixture(tmp_path):
     want = orclib.forward_f32(model, boxed)
     raw = np.loadtxt(tmp_path / "raw.txt").astype(np.float32)
     assert np.array_equal(raw.view(np.uint32), want.view(np.uint32))
+    # --precision fp16: the same weight files on the matrix cores; approximate (tolerance of the fp16 path), same plumbing
+    env16 = dict(os.environ, YOLO2_DUMP_REGION_RAW=str(tmp_path / "raw16.txt"))
+    r16 = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names"),
+                          "--weights", str(tmp_path / "weights"), "--input", str(ppm), "--output", str(tmp_path / "pred16"),
+                          "--thresh", "0.5", "--backend", "hip", "--precision", "fp16", "--batch", "3"],
+                         capture_output=True, text=True, env=env16, cwd=str(tmp_path))
+    assert r16.returncode == 0, r16.stdout + r16.stderr
+    assert "precision: fp16" in r16.stdout and "Predicted in" in r16.stdout
+    raw16 = np.loadtxt(tmp_path / "raw16.txt").astype(np.float32)
+    assert np.abs(raw16 - want).max() <= 0.03 and not np.array_equal(raw16, want)
     # the library entry on the fixture frame == the compiled reference's tensor
     ctx = hipdrv.Yolo2Hip(0)
     ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
