@@ -1585,7 +1585,16 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
     int first = 0;
     for (int i = 0; i < nl; ++i) {
         yolo2_hip_ctx *l = nullptr;
-        const int frames = batch / nl + (i < batch % nl ? 1 : 0);
+        // The remainder goes to the LAST lanes: the first lane's launches are enqueued first in every step and it is the one that
+        // finishes last (kernel trace: by 0.6-3 ms of a 20 ms step at batch 64), so it gets the smaller share.
+        int frames = batch / nl + (i >= nl - batch % nl ? 1 : 0);
+        if (const char *sp = getenv("YOLO2_LANE_SPLIT")) {   // diagnostic: "20,22,22" (must sum to the batch)
+            std::vector<int> v;
+            for (const char *q = sp; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+            int sum = 0;
+            for (int x : v) sum += x;
+            if ((int)v.size() == nl && sum == batch) frames = v[i];
+        }
         int rc = make_lane(c, &l);
         if (rc == YOLO2_SUCCESS) {
             c->lanes.push_back(l);
