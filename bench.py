@@ -435,8 +435,8 @@ def main():
     if rank == 0:
         fps = world * B * args.steps / dt
         paths = ctx.layer_paths()
-        lanes = ctx.num_lanes()          # every layer is `lanes` concurrent part-batch launches (3 at batch 64: 22 + 21 + 21)
-        Bl = (B + lanes - 1) // lanes    # frames per launch of lane 0, the one the per-layer hipEvents time
+        lanes = ctx.num_lanes()          # every layer is `lanes` concurrent part-batch launches (3 at batch 64: 21 + 21 + 22)
+        Bl = B // lanes                  # frames per launch of lane 0, the one the per-layer hipEvents time (the remainder goes to the last lanes)
         # dominant kernel = the conv kernel instantiation with the largest total time
         groups = {}
         fused = ctx.pool_fused_layers()      # convs that run as k_conv_i16_pool (conv + leaky + 2x2 pool in one kernel)
