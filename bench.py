@@ -114,7 +114,7 @@ def cpu_baseline(model, frames, gpu_regions):
     return out
 
 
-INT16_DEVICE_SOURCES = ("kernels_int16.hpp", "kernels_pre.hpp", "layout.hpp")
+INT16_DEVICE_SOURCES = ("kernels_int16.hpp", "conv_common.hpp", "kernels_pre.hpp", "layout.hpp")
 
 
 def kernel_source_hash():
@@ -151,6 +151,68 @@ def hbm_traffic_per_launch(ks, batch):
         return doc["kernels"][f"y2::k_conv_i16<KS={ks},...>"]["hbm_bytes_per_launch"], f"{TRAFFIC_FILE} (tools/traffic.sh)"
     except KeyError:
         return None, f"{TRAFFIC_FILE} holds no entry for KS={ks}"
+
+
+def leave_job(rank, msg, ctx=None, code=1):
+    """Every rank calls this together (after ydist.all_ok said that some rank failed): say why, tear down, exit non-zero."""
+    print(f"bench.py[rank {rank}]: {msg}", file=sys.stderr, flush=True)
+    try:
+        if ctx is not None:
+            ctx.close()
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    finally:
+        sys.exit(code)
+
+
+def init_context(precision, rank, world, local_rank, dev):
+    """Phase 1 (local): the synthetic model on rank 0, a context on this rank's GPU.  Phase 2 (collective, only with a process
+    group): the 128-byte communicator id travels over torch.distributed, every rank joins the LIBRARY's RCCL communicator and
+    calls the library's _bcast loader - whose failure is collective (include/yolo2_hip.h): every rank raises or none does.
+    After each phase the ranks agree (ydist.all_ok) and leave together if any of them failed, so no rank is ever left alone
+    in a barrier; init_process_group carries a timeout for the case of a rank that died outright."""
+    model, ctx, err = None, None, None
+    try:
+        model = synth.SynthModel(seed=1) if rank == 0 else None
+        ctx = hipdrv.Yolo2Hip(local_rank)
+    except Exception as e:      # noqa: BLE001 - reported below, on every rank
+        err = e
+    if not ydist.all_ok(err is None, dev):
+        leave_job(rank, f"context creation failed: {err}" if err else "another rank failed to create its context", ctx)
+    try:
+        if dist.is_initialized():   # the library's own RCCL broadcast (shared with the C host's --devices path)
+            ctx.rccl_init_rank(ydist.exchange_unique_id(hipdrv.rccl_unique_id, dev), world, rank)
+            if precision == "fp16":
+                ctx.load_model_fp32_bcast(model, root=0)
+            else:
+                ctx.load_model_bcast(model, root=0)
+        elif precision == "fp16":
+            ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+        else:
+            ctx.load_model(model)
+    except Exception as e:      # noqa: BLE001
+        err = e
+    if not ydist.all_ok(err is None, dev):
+        leave_job(rank, f"weight load failed: {err}" if err else "another rank failed to load the weights", ctx)
+    return model, ctx
+
+
+def rccl_record(ctx, B, steps, dt_rank, dev):
+    """The bench line's "rccl" object: what the library's communicator reports on rank 0 (nranks is ncclCommCount, not WORLD_SIZE),
+    the broadcast it carried, the file RCCL was resolved from - and one row per rank (its own view of the communicator, its own
+    time for the timed region), so that "did RCCL see N ranks" and "did every rank do its share" are answerable from the record."""
+    if not dist.is_initialized():
+        return None, None
+    info = ctx.rccl_info()
+    rows = ydist.gather_row([info["rank"], info["device"], info["nranks"], info["bcast_ms"], dt_rank], dev)
+    per_rank = [{"rank": int(r[0]), "device": int(r[1]), "nranks_seen": int(r[2]), "bcast_ms": float(r[3]),
+                 "frames_per_s": B * steps / float(r[4]), "timed_region_s": float(r[4])} for r in rows]
+    rec = {"nranks": info["nranks"], "rank0_bcast_ms": info["bcast_ms"], "bytes": info["bytes"], "lib_path": info["lib_path"],
+           "version": info["version_str"], "version_code": info["version"], "bcasts": info["bcasts"],
+           "all_ranks_agree_on_nranks": bool(all(p["nranks_seen"] == info["nranks"] for p in per_rank)),
+           "note": "from the library's own communicator (ncclCommCount / ncclCommUserRank / ncclCommCuDevice, dladdr of ncclBroadcast); "
+                   "torch.distributed carries only the 128-byte id, the barriers and the timing reductions"}
+    return rec, per_rank
 
 
 print_record = None                # set by main(): writes the one JSON line to the original stdout
@@ -202,13 +264,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
     """configs[3]: YOLOv2 fp16 MFMA path.  Same protocol as the int16 bench; rank 0 builds the fp32 weight set and ONE
     broadcast (the same one the int16 bench uses) puts it on every GPU."""
     B = args.batch
-    model = synth.SynthModel(seed=1) if rank == 0 else None
-    ctx = hipdrv.Yolo2Hip(local_rank)
-    if dist.is_initialized():   # the library's own RCCL broadcast (shared with the C host's --devices path)
-        ctx.rccl_init_rank(ydist.exchange_unique_id(hipdrv.rccl_unique_id, dev), world, rank)
-        ctx.load_model_fp32_bcast(model, root=0)
-    else:
-        ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    model, ctx = init_context("fp16", rank, world, local_rank, dev)
     lo, hi = ydist.shard_range(B * world, rank, world)
     frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
     region = torch.empty((B, 425, 13, 13), dtype=torch.float32, device=dev)
@@ -232,6 +288,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
         step()
     fence()
     dt = time.perf_counter() - t0
+    rccl, per_rank = rccl_record(ctx, B, args.steps, dt, dev)
     if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -243,6 +300,8 @@ def bench_fp16(args, world, rank, local_rank, dev):
                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic"}
         result.update({k: rec[k] for k in ("config", "roofline", "whole_pass", "layer_ms", "conv_ms_per_step")})
+        if rccl is not None:
+            result["rccl"], result["per_rank"] = rccl, per_rank
         if world == 1 and not args.no_cpu_baseline:
             err, cdt = fp16_error_vs_fp32(model, frames[0].cpu().numpy(), region[0].cpu().numpy(), 1)
             result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
@@ -383,7 +442,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # a rank that dies outright must not hang the others for ever: collectives of the process group give up after this long
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("YOLO2_BENCH_DIST_TIMEOUT_S", "300"))))
 
     B = args.batch
     if args.precision == "fp16":
@@ -392,19 +454,18 @@ def main():
     # library's (yolo2_hip_load_weights_int16_bcast: ncclBroadcast from librccl.so over its own communicator, the same
     # routine the C host's `yolov2_detect --devices` uses); torch.distributed only carries the 128-byte communicator id,
     # the barrier and the max-over-ranks of the timing.
-    model = synth.SynthModel(seed=1) if rank == 0 else None
-    ctx = hipdrv.Yolo2Hip(local_rank)
-    if dist.is_initialized():
-        ctx.rccl_init_rank(ydist.exchange_unique_id(hipdrv.rccl_unique_id, dev), world, rank)
-        ctx.load_model_bcast(model, root=0)
-    else:
-        ctx.load_model(model)
-    ctx.set_batch(B)
-
-    # ---- this rank's shard of the global synthetic batch, resident in HBM before timing
-    lo, hi = ydist.shard_range(B * world, rank, world)
-    frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
-    region = torch.empty((B, 425, 13, 13), dtype=torch.int16, device=dev)
+    model, ctx = init_context("int16", rank, world, local_rank, dev)
+    # ---- the batch plan and this rank's shard of the global synthetic batch, resident in HBM before timing (local phase 3)
+    err = None
+    try:
+        ctx.set_batch(B)
+        lo, hi = ydist.shard_range(B * world, rank, world)
+        frames = torch.from_numpy(synth.frames(7, hi - lo, first=lo)).to(dev)
+        region = torch.empty((B, 425, 13, 13), dtype=torch.int16, device=dev)
+    except Exception as e:      # noqa: BLE001
+        err = e
+    if not ydist.all_ok(err is None, dev):
+        leave_job(rank, f"set_batch / frame upload failed: {err}" if err else "another rank failed in set_batch / frame upload", ctx)
     stream = torch.cuda.current_stream(dev)
 
     def step():
@@ -425,6 +486,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
+    rccl, per_rank = rccl_record(ctx, B, args.steps, dt, dev)
     if dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -502,6 +564,8 @@ def main():
             "layer_ms": [round(float(x), 4) for x in layer_ms],
             "conv_ms_per_step": conv_ms,
         }
+        if rccl is not None:
+            result["rccl"], result["per_rank"] = rccl, per_rank
         if world == 1 and not args.no_cpu_baseline:
             idx = [0, B - 1]    # first frame of the first lane, last frame of the last
             result["cpu_baseline"] = cpu_baseline(model, [frames[i].cpu().numpy() for i in idx],

@@ -135,7 +135,8 @@ uint64_t memory_get_phys_addr(void *virt_addr);
 void     memory_flush_cache(void *addr, size_t size);
 void     memory_invalidate_cache(void *addr, size_t size);
 
-/* HBM buffers for callers that manage residency themselves. */
+/* HBM buffers for callers that manage residency themselves.  yolo2_hip_alloc allocates on the calling thread's CURRENT
+ * device (the driver tier is a one-device interface); a caller that holds contexts on several devices uses _alloc_on. */
 int  yolo2_hip_alloc(size_t bytes, uint64_t *dev_addr);
 void yolo2_hip_free(uint64_t dev_addr);
 int  yolo2_hip_memcpy_h2d(uint64_t dst, const void *src, size_t bytes);
@@ -153,7 +154,10 @@ typedef struct yolo2_hip_ctx yolo2_hip_ctx; /* one per device; thread-compatible
 #define YOLO2_FRAME_ELEMS  (3 * 416 * 416)
 
 int  yolo2_hip_create(int device, yolo2_hip_ctx **ctx);
-void yolo2_hip_destroy(yolo2_hip_ctx *ctx);
+void yolo2_hip_destroy(yolo2_hip_ctx *ctx);   /* also leaves the context's RCCL communicator, if it joined one */
+int  yolo2_hip_ctx_device(yolo2_hip_ctx *ctx);
+/* HBM on the context's device, whatever device the calling thread has current (and leaves that binding in force) */
+int  yolo2_hip_alloc_on(yolo2_hip_ctx *ctx, size_t bytes, uint64_t *dev_addr);
 
 /* Weights as yolov2_hls_ps holds them after load_weights (yolo2_model.cpp:158-227): the
  * weights_reorg_int16 stream with the per-layer file pad already stripped
@@ -220,6 +224,17 @@ int yolo2_hip_load_weights_fp32_dev(yolo2_hip_ctx *ctx, uint64_t weights_reorg_d
 int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch, uint64_t region_dev,
                              void *stream);
 int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *ctx, const float *frames, int batch, float *region);
+/* The kernel the fp16 pass runs for layer `layer_idx` at the current batch (after the first run at that batch; "" before).
+ * The selection is made ONCE per (weights, batch) into a launch table; the YOLO2_F16_* A/B switches are read when the weights
+ * are loaded, never on the launch path. */
+const char *yolo2_hip_fp16_layer_kernel(yolo2_hip_ctx *ctx, int layer_idx);
+/* The extent check every step of that table passes before it may be launched, on explicit numbers (testable without a GPU):
+ * a kernel of store kind `store` (0 = stores the full-resolution tensor only and ignores a fused pool, 1 = full-resolution or
+ * pooled according to `pool`, 2 = pooled only) for a B x H x W conv writing items of Cp_out halves, channels
+ * [out_ch_off, out_ch_off + n_store), into a tensor of dst_B x dst_H x dst_W pixels with dst_Cp halves per item.
+ * YOLO2_SUCCESS, or YOLO2_ERROR with yolo2_hip_last_error() naming the mismatch. */
+int yolo2_hip_f16_store_check(int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store, int dst_B,
+                              int dst_H, int dst_W, int dst_Cp);
 
 /* Copies layer `layer_idx`'s output of frame `frame` from the last run into the reference's
  * [C][H][W8] int16 layout (pad columns zero) -- the yolov2_region_*_hw.txt style parity hook
@@ -360,6 +375,24 @@ int  yolo2_hip_load_weights_int16_bcast(yolo2_hip_ctx *ctx, const int16_t *weigh
                                         const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q, int root);
 int  yolo2_hip_load_weights_fp32_bcast(yolo2_hip_ctx *ctx, const float *weights_reorg, size_t n_weights,
                                        const float *bias, size_t n_bias, int root);
+/* Failure of a _bcast loader is COLLECTIVE: every rank first does its local part (the root: argument checks, allocation, H2D;
+ * the others: allocation), the ranks agree on a status word (one ncclAllReduce(min) of an int), and either all of them run the
+ * broadcast or all of them return an error; a second agreement follows the per-rank load.  A root-side error therefore never
+ * leaves the other ranks blocked inside ncclBroadcast.  A rank whose process dies is the launcher's business. */
+
+/* What the communicator itself reports (ncclCommCount / ncclCommUserRank / ncclCommCuDevice / ncclGetVersion), the file the
+ * RCCL entry points were resolved from (dladdr: a process that already mapped a librccl with the same soname - torch ships one -
+ * gets that copy from dlopen), and the most recent weight broadcast through it.  "Did RCCL see N ranks" is answered by nranks. */
+typedef struct {
+    int nranks, rank, device;
+    int version;                 /* ncclGetVersion: e.g. 22606 */
+    int bcasts;                  /* weight broadcasts run through this communicator */
+    double last_bcast_ms;        /* host wall time of the last one (enqueue to stream-synchronised), this rank */
+    uint64_t last_bcast_bytes;   /* bytes each rank received / the root sent per peer */
+    char lib_path[256];
+} yolo2_hip_rccl_info_t;
+int  yolo2_hip_rccl_info(yolo2_hip_ctx *ctx, yolo2_hip_rccl_info_t *out);
+int  yolo2_hip_multi_rccl_info(yolo2_hip_multi *m, yolo2_hip_rccl_info_t *out);   /* model (a): rank/device of member 0 */
 
 /* ------------------------------------------------------------------- tier 3: helpers */
 

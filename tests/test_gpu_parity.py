@@ -519,6 +519,11 @@ def test_fp16_mfma_path_vs_fp32_reference():
     # batch consistency: a frame alone == the same frame inside a batch (deterministic kernel)
     single = ctx.run_batch_fp16_host(frames[2:3])
     assert np.array_equal(single[0], region[2])
+    # the launch table (built once per batch; the YOLO2_F16_* switches are latched when the weights are loaded)
+    kern = ctx.fp16_layer_kernels()
+    assert kern[0] == "k_conv0_pool_mfma" and kern[2] == "k_conv_f16_c32_pool" and kern[30].startswith("k_gemm1_f16_p")
+    assert kern[4].startswith("k_conv_f16_halo_p") and kern[22].startswith("k_conv_f16_halo<256")
+    assert 1 not in kern and 3 not in kern, "pools fused into the convs before them must have no launch of their own"
     ctx.close()
 
 
@@ -816,6 +821,18 @@ def test_register_file_and_dma_buffers(driver):
     want_leaky = orclib.conv_i16(x, wr, b, C, N, K, 1, W, H, pad, 1, Qw, Qai, Qao, Qb)
     assert np.array_equal(out(), want_leaky) and not np.array_equal(want_leaky, y)
     assert L.yolo2_hip_driver_calls() == calls0 + 2
+    # a register-level start has no return value: its status is latched at 0xf0 (beyond the IP's own map), so a client polling
+    # ap_done can tell a rejected layer from a finished one
+    assert L.yolo2_read_reg(0xf0) == 0
+    L.yolo2_write_reg(0x50, 7)                    # kernel size 7: outside the accelerator's limits
+    L.yolo2_write_reg(0x00, 0x01)
+    assert L.yolo2_read_reg(0x00) == 0x0e and ctypes.c_int32(L.yolo2_read_reg(0xf0)).value == hipdrv.YOLO2_ERROR
+    assert b"limits" in L.yolo2_hip_last_error()
+    L.yolo2_write_reg(0xf0, 0)                    # read-only
+    assert ctypes.c_int32(L.yolo2_read_reg(0xf0)).value == hipdrv.YOLO2_ERROR
+    L.yolo2_write_reg(0x50, K)
+    L.yolo2_write_reg(0x00, 0x01)
+    assert L.yolo2_read_reg(0xf0) == 0 and np.array_equal(out(), want_leaky)
     L.dma_buffer_free(ctypes.byref(bufs[0]))
     assert bufs[0].virt_addr is None and L.memory_get_phys_addr(ctypes.c_void_p(bufs[1].virt_addr)) == bufs[1].phys_addr
     L.dma_buffer_cleanup()                        # frees what is still tracked

@@ -179,10 +179,48 @@ def test_multi_images_entry_and_rank_api_with_rccl():
     frame = synth.frames(7, 1)
     region, q = ctx.run_batch_host(frame)
     assert q == 9 and np.array_equal(region[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    info = ctx.rccl_info()                      # what the communicator itself reports (bench.py's "rccl" object)
+    assert (info["nranks"], info["rank"], info["device"], info["bcasts"]) == (1, 0, 0, 1)
+    assert info["bytes"] == 2 * (net.N_WEIGHTS + net.N_BIAS) + 4 * (3 + 3 * 64) and info["bcast_ms"] > 0
+    assert "rccl" in info["lib_path"] and info["version"] >= 20000
     ctx.load_model_fp32_bcast(model, root=0)
     f32 = ctx.run_frame_fp32_host(frame[0])
     assert np.array_equal(f32.reshape(-1).view(np.uint32), FULL["f32/std/region_raw_f32"].view(np.uint32))
-    ctx.rccl_finalize()
+    assert ctx.rccl_info()["bcasts"] == 2
+    # a root-side failure is carried INTO the collective (status agreement), not returned in front of it: the call fails with
+    # the root's own message, the communicator stays usable, the model loaded before is still in force
+    w = np.ascontiguousarray(model.weights_i16()[:1000])
+    b = np.ascontiguousarray(model.bias_i16())
+    import ctypes as C
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    wq, bq, aq = (np.ascontiguousarray(a, dtype=np.int32) for a in (model.weight_q, model.bias_q, model.act_q))
+    rc = hipdrv.lib().yolo2_hip_load_weights_int16_bcast(ctx._h, vp(w), w.size, vp(b), b.size, vp(wq), wq.size, vp(bq), bq.size, vp(aq), aq.size, 0)
+    assert rc == hipdrv.YOLO2_ERROR and b"too small" in hipdrv.lib().yolo2_hip_last_error()
+    assert ctx.rccl_info()["bcasts"] == 2       # no broadcast ran
+    region2, _ = ctx.run_batch_host(frame)
+    assert np.array_equal(region2, region)
+    ctx.close()                                 # destroy leaves the communicator (no explicit rccl_finalize) ...
+    ctx = hipdrv.Yolo2Hip(0)                    # ... so a new context, wherever it is allocated, can join a new one
+    ctx.rccl_init_rank(hipdrv.rccl_unique_id(), 1, 0)
+    assert ctx.rccl_info()["bcasts"] == 0
+    ctx.close()
+
+
+def test_postprocess_rejects_a_region_tensor_it_cannot_reach():
+    """yolo2_hip_postprocess_* runs on the context's device; an address that is not device-accessible memory is refused
+    (on a multi-GPU box: also a tensor that lives in another GPU's HBM - allocate with yolo2_hip_alloc_on)."""
+    ctx = hipdrv.Yolo2Hip(0)
+    host = np.zeros(net.REGION_ELEMS if hasattr(net, "REGION_ELEMS") else 425 * 169, dtype=np.int16)
+    with pytest.raises(hipdrv.Yolo2HipError, match="not device-accessible"):
+        hipdrv.postprocess(ctx, host.ctypes.data, 1, [640], [480], 0.25, 0.45, final_q=9)
+    import ctypes as C
+    a = C.c_uint64(0)
+    hipdrv.check(hipdrv.lib().yolo2_hip_alloc_on(ctx._h, host.nbytes, C.byref(a)), "alloc_on")
+    hipdrv.check(hipdrv.lib().yolo2_hip_memset(a, 0, host.nbytes), "memset")
+    out = hipdrv.postprocess(ctx, a.value, 1, [640], [480], 0.6, 0.45, final_q=9)
+    assert int(out["counts"][0]) == 0           # an all-zero tensor: objectness 0.5 everywhere, below the threshold
+    hipdrv.lib().yolo2_hip_free(a)
+    assert hipdrv.lib().yolo2_hip_ctx_device(ctx._h) == 0
     ctx.close()
 
 

@@ -187,3 +187,85 @@ def test_fast_div_magic_is_exact_for_the_layer_geometries():
         for n in ns.tolist():
             n &= 0xFFFFFFFF
             assert fdiv(n, m, s) == n // d, (d, n)
+
+
+# ------------------------------------------------------------------ round 3: launch-time extent check, failure containment
+
+def test_fp16_plan_store_check_rejects_the_layer6_mismatch():
+    """Round 2's abort inside run_batch_fp16: a kernel that stores the FULL-resolution tensor and ignores a fused
+    pool (store kind 0: the persistent halo kernel) was handed layer 6's POOLED tensor - 104 x 104 offsets into a 52 x 52 tensor.
+    The check every step of the fp16 launch table passes turns that into YOLO2_ERROR before anything is launched; here on explicit
+    numbers, no GPU needed."""
+    L = hipdrv.lib()
+    B = 128
+    ok = lambda *a: L.yolo2_hip_f16_store_check(*a)
+    # the plan as it is: layer 6 on a pool-honouring kernel (kind 1) with pool = 1 into the 52 x 52 x 128 tensor of layer 7
+    assert ok(1, 1, B, 104, 104, 128, 0, 128, B, 52, 52, 128) == hipdrv.YOLO2_SUCCESS
+    # ... layer 4 on the full-resolution-only persistent kernel into its own 104 x 104 tensor
+    assert ok(0, 0, B, 104, 104, 128, 0, 128, B, 104, 104, 128) == hipdrv.YOLO2_SUCCESS
+    # the deliberately mismatched plan: full-resolution-only kernel, pooled destination (what round 2 launched for one commit)
+    assert ok(0, 1, B, 104, 104, 128, 0, 128, B, 52, 52, 128) == hipdrv.YOLO2_ERROR
+    assert b"cannot fuse the pool" in L.yolo2_hip_last_error()
+    # the same kernel with the pool flag cleared but still the pooled tensor: caught by the geometry
+    assert ok(0, 0, B, 104, 104, 128, 0, 128, B, 52, 52, 128) == hipdrv.YOLO2_ERROR
+    assert b"104 x 104" in L.yolo2_hip_last_error() and b"52 x 52" in L.yolo2_hip_last_error()
+    # a pooled store into the full-resolution tensor, a batch mismatch, channels outside the item, item size mismatch
+    assert ok(2, 1, B, 104, 104, 128, 0, 128, B, 104, 104, 128) == hipdrv.YOLO2_ERROR
+    assert ok(1, 0, B, 52, 52, 256, 0, 256, B // 2, 52, 52, 256) == hipdrv.YOLO2_ERROR
+    assert ok(1, 0, B, 13, 13, 1280, 256, 1024, B, 13, 13, 1280) == hipdrv.YOLO2_SUCCESS        # conv 24 into the concat tensor
+    assert ok(1, 0, B, 13, 13, 1280, 512, 1024, B, 13, 13, 1280) == hipdrv.YOLO2_ERROR          # ... one block too far
+    assert ok(1, 0, B, 13, 13, 1024, 0, 1024, B, 13, 13, 1280) == hipdrv.YOLO2_ERROR
+    assert ok(7, 0, B, 13, 13, 1024, 0, 1024, B, 13, 13, 1024) == hipdrv.YOLO2_ERROR            # unknown store kind
+
+
+def _containment_worker(rank, world, port, q, fail_rank):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "yolo-fpga-accelerator_amd"))
+    from yolo2_amd import dist as ydist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    dev = torch.device("cpu")
+    err = None
+    try:
+        if rank == fail_rank:
+            raise RuntimeError("local step failed on purpose")
+    except RuntimeError as e:
+        err = e
+    ok = ydist.all_ok(err is None, dev)          # every rank learns that SOME rank failed ...
+    rows = ydist.gather_row([rank, 10.0 + rank], dev)
+    q.put((rank, ok, rows.tolist()))
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 3)                     # ... and all of them leave together, non-zero
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 1])
+def test_bench_failure_containment_world2_gloo(fail_rank):
+    """bench.py's phases end with ydist.all_ok: when one rank's local step fails, NO rank proceeds to the next barrier alone -
+    all of them see ok == False and exit non-zero; per-rank rows travel with one all-gather (the `per_rank` field)."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_containment_worker, args=(r, 2, port, q, fail_rank)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    want_ok = fail_rank < 0
+    assert [r[1] for r in res] == [want_ok, want_ok]
+    assert all(p.exitcode == (0 if want_ok else 3) for p in ps), [p.exitcode for p in ps]
+    for r in res:
+        assert r[2] == [[0.0, 10.0], [1.0, 11.0]]
+
+
+def test_fp16_launch_path_reads_no_environment():
+    """The fp16 kernel-family switches are latched once per weight load (F16Switches::from_env); run_batch_fp16 and the table
+    builder's selection logic must not call getenv (15 getenv sites per conv layer per call)."""
+    src = open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "yolo2_fp16.hip")).read()
+    body = src[src.index("static int build_f16_plan"):]
+    sel, run = body[:body.index("P.batch = B;")], body[body.index('extern "C" int yolo2_hip_run_batch_fp16('):]
+    assert "getenv" not in sel and "getenv" not in run
+    assert src.count("from_env()") >= 2 and "getenv" in src[src.index("static F16Switches from_env"):src.index("struct F16Step;")]

@@ -20,7 +20,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "kernels_int16.hpp"   // ConvArgs, flat_of, xcd_partition
+#include "conv_common.hpp"   // ConvArgs, flat_of, xcd_partition, k_repack_weights, k_pool_ref
 #include "layout.hpp"
 
 namespace y2 {
@@ -222,6 +222,52 @@ __global__ void k_unpack_dense_f32(const float *__restrict__ in, float *__restri
     if (t >= n) return;
     const int x = (int)(t % W), y = (int)((t / W) % H), c = (int)((t / ((long)W * H)) % C), b = (int)(t / ((long)W * H * C));
     out[t] = in[(kLead + (long)(c >> 2) * cg_stride + (long)b * PL + (long)(y + 1) * Wp + x) * 4 + (c & 3)];
+}
+
+
+// ------------------------------------------------------------------ one-thread-per-output reference-layout kernels
+// (the independent second implementation behind yolo2_execute_conv_layer_f32 and yolo2_hip_run_frame_fp32_host)
+// fp32 twin, reference operation order with no FMA contraction (core_compute.cpp:121-172, :201-205)
+__global__ void k_conv_ref_f32(const float *__restrict__ in, float *__restrict__ out, const float *__restrict__ w,
+                               const float *__restrict__ bias, int C, int N, int K, int stride, int W, int H,
+                               int OW, int OH, int pad, int leaky)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= N * OH * OW) return;
+    const int x = t % OW, y = (t / OW) % OH, m = t / (OW * OH);
+    const int W8 = (W + 7) & ~7, OW8 = (OW + 7) & ~7, KK = K * K;
+    const int m0 = m / kTm * kTm, tm = m - m0, tm_min = min(kTm, N - m0);
+    float acc = bias[m];
+    for (int n0 = 0; n0 < C; n0 += kTn) {
+        const int tn_min = min(kTn, C - n0);
+        const float *wb = w + (long)m0 * C * KK + (long)tm_min * n0 * KK;
+        for (int i = 0; i < K; ++i)
+            for (int j = 0; j < K; ++j) {
+                const int sy = y * stride + i - pad, sx = x * stride + j - pad;
+                const bool inb = sy >= 0 && sy < H && sx >= 0 && sx < W;
+                float ps = 0.f;
+                for (int tt = 0; tt < kTn; ++tt) {
+                    const float wv = tt < tn_min ? wb[(long)(i * K + j) * tm_min * tn_min + tm * tn_min + tt] : 0.f;
+                    const float xv = (inb && tt < tn_min) ? in[((long)(n0 + tt) * H + sy) * W8 + sx] : 0.f;
+                    ps = __fadd_rn(ps, __fmul_rn(wv, xv));
+                }
+                acc = __fadd_rn(acc, ps);
+            }
+    }
+    if (leaky && acc < 0.0f) acc = __fmul_rn(acc, 0.1f);
+    out[((long)m * OH + y) * OW8 + x] = acc;
+}
+
+// legacy reorg (yolo2_model.cpp:112-129, 358-376) in the reference's [C][H][W8] layout, one frame
+__global__ void k_reorg_ref_f32(const float *__restrict__ in, float *__restrict__ out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // over 256*13 rows x 13 columns
+    if (t >= 256 * 13 * 13) return;
+    const int kr = t / 13, cc = t - kr * 13;
+    const int p = kr * 13 + cc;                            // index into the permuted dense tensor
+    const int i = p % 26, rest = p / 26, j = rest % 416, k = rest / 416;
+    const int d = (2 * i + k % 2) + 52 * (2 * j + k / 2);  // index into the dense 64 x 26 x 26 input
+    out[(size_t)kr * 16 + cc] = in[(size_t)(d / 26) * 32 + d % 26];
 }
 
 }  // namespace y2

@@ -1,0 +1,187 @@
+// y2_internal.hpp -- what the translation units of libyolo2_hip.so share (nothing here is part of the C ABI).
+//
+//   yolo2_hip.hip     errors, model tables, context lifecycle, profiling, pre-processing, host-buffer streaming entries
+//   yolo2_driver.hip  tier 1: the reference's accelerator-driver interface (linux_app/include/yolo2_accel_linux.h,
+//                     dma_buffer_manager.h): device state, buffers, register file, per-layer calls
+//   yolo2_int16.hip   the int16 path: weight loading / arithmetic-form proofs, launch planning, autotune, run_batch_int16
+//   yolo2_fp16.hip    the fp16 MFMA path: weight packing, per-context launch table, run_batch_fp16
+//   yolo2_fp32.hip    the exact fp32 path (tiled and one-thread-per-output)
+//   yolo2_post.hip    region layer + boxes + NMS;   yolo2_multi.hip  frame sharding + the RCCL weight broadcast
+// Every non-template kernel is launched from exactly one of them (its kernels_*.hpp is included there only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/yolo2_hip.h"
+#include "conv_common.hpp"
+#include "layout.hpp"
+
+// ---------------------------------------------------------------------------- errors (yolo2_hip.hip)
+
+// stores the message for yolo2_hip_last_error() (thread-local) and returns `code`
+int y2_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+#define fail y2_fail
+
+#define HIP_TRY(expr, code)                                                                      \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) return fail(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// ---------------------------------------------------------------------------- model table (yolo2_hip.hip)
+
+enum LType { L_CONV, L_MAX, L_ROUTE, L_REORG, L_REGION };
+struct LayerDesc {
+    LType type;
+    int c, h, w, n, size, leaky;
+};
+// config/yolov2.cfg as parsed by the reference; the C host re-derives the same
+// table from the .cfg file and checks it against this one before using the batched entry.
+extern const LayerDesc kNet[32];
+
+static inline unsigned blocks_for(long n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline long packed_weight_elems(int C, int N, int K)
+{
+    return (long)((N + y2::kTm - 1) / y2::kTm) * ((C + y2::kTn - 1) / y2::kTn) * K * K * 128;
+}
+
+// ---------------------------------------------------------------------------- launch plan of one conv launch (int16 / fp32 tiled)
+
+constexpr int kMaxTileItems = 2048;  // 8 staging registers x 256 threads (k_conv_i16 NST <= 8)
+
+struct ConvPlan {
+    int C = 0, N = 0, K = 0, H = 0, W = 0, leaky = 0;
+    int Qw = 0, Qa_in = 0, Qa_out = 0, Qb = 0;
+    int path = 0;  // 0 = form A, 1 = form B (pre-shifted accumulator), 3 = form C (packed int16), 4 = form D (C, shift-free), 2 = 64-bit
+    int P = 8;
+    int mb_count = 0;          // output-channel blocks this launch covers (0 = all of the layer)
+    int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
+    int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
+    int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
+    int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
+    int pool_fused = 0;        // conv + leaky + 2x2 pool in one kernel (k_conv_i16_pool): 1 = pooled tensor only, 2 = + full tensor
+    int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
+                               // fewer co-resident workgroups finish sooner each, which shortens the
+                               // idle tail of layers that are only a few workgroup-generations long
+    dim3 grid;
+    int lds_bytes = 0;
+    y2::ConvArgs args;
+};
+
+// ---------------------------------------------------------------------------- the context
+
+struct Tensor {
+    y2::ActGeom g;
+    int2 *d = nullptr;
+};
+
+// Staging for the host-buffer entries (run_frames / run_images): two buffer sets and three streams
+// (upload, kernels, download), kept with the context and grown on demand so that a caller streaming
+// chunk after chunk does not pay pinned-memory allocation per call.
+struct PipeBufs {
+    size_t host_in = 0, dev_in = 0;   // capacities in bytes (dev_in: raw image bytes, 0 for float frames)
+    int batch = 0;
+    uint8_t *hin[2] = {nullptr, nullptr}, *dbytes[2] = {nullptr, nullptr};
+    float *din[2] = {nullptr, nullptr};
+    int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
+    hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
+    hipEvent_t e_in[2] = {nullptr, nullptr}, e_run[2] = {nullptr, nullptr}, e_out[2] = {nullptr, nullptr};
+};
+
+struct F16Plan;   // yolo2_fp16.hip: the per-context launch table of the fp16 path
+
+struct yolo2_hip_ctx {
+    PipeBufs pipe;
+    int device = 0;
+    bool weights_loaded = false;
+    short *wpk = nullptr;      // all layers, packed
+    short *bias_pk = nullptr;  // all layers, padded to 32
+    long wpk_off[YOLO2_N_CONV], bias_off[YOLO2_N_CONV];
+    int maxsum[YOLO2_N_CONV], maxbias[YOLO2_N_CONV];
+    std::vector<int> weight_q, bias_q, act_q;
+    ConvPlan plan[32];                 // per conv layer: the launch covering most output-channel blocks
+    std::vector<ConvPlan> extra[32];   // further launches for blocks that need another arithmetic form
+    std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV], maxabs_mb[YOLO2_N_CONV];
+    std::vector<signed char> wscale_mb[YOLO2_N_CONV];   // log2 of the factor each block's packed weights currently carry (form D)
+    int *mb_lists = nullptr;           // device: block index lists of all split layers
+    // Lanes: a batch is run as part-batches on internal streams (forked from / joined to the
+    // caller's stream with events).  Every layer is then several concurrent launches, and the idle tail of
+    // one (a layer is only a few workgroup-generations long at batch 64) is filled by the others.
+    // A lane is a child context that shares the parent's weights.
+    std::vector<yolo2_hip_ctx *> lanes;
+    std::vector<int> lane_first;       // first frame of each lane within the batch
+    std::vector<yolo2_hip_ctx *> f16_lanes;   // fp16 path: two half-batch lanes (share wh / biasf / w0f)
+    bool is_lane = false, laned = false;
+    hipStream_t lane_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool fuse_pool[32] = {false};      // conv layer i stores the pooled tensor of layer i+1 itself (k_conv_i16_pool)
+    ConvPlan fplan[32];                // the fused launches of those layers (plan / extra keep the unfused ones)
+    std::vector<ConvPlan> fextra[32];
+    int path_counts[YOLO2_N_CONV][5];
+    int reorg_shift = 0, final_q = 0;
+    int batch = 0;
+    Tensor t_in, t_out[32], t_cat;
+    // ---- fp16 MFMA path
+    struct HalfTensor {
+        int C = 0, Cp = 0, H = 0, W = 0, Wp = 0, PL = 0, B = 0;
+        size_t items = 0;
+        _Float16 *d = nullptr;
+    };
+    bool f16_loaded = false;
+    _Float16 *wh = nullptr;
+    float *biasf = nullptr;
+    float *w0f = nullptr;  // layer 0: [27][32] fp32 weights + [32] bias for the fused conv0+pool kernel
+    float *wf32 = nullptr, *bf32 = nullptr;   // the fp32 blobs as loaded (reference stream order), for the exact fp32 pass
+    F16Plan *f16_plan = nullptr;              // launch table of the fp16 pass (built once per (weights, batch); owned)
+    // ---- tiled exact fp32 path (kernels_f32.hpp): packed weights [mb][cg][tap][32][4] floats, items of 4 floats
+    float *wpkf = nullptr, *biasf32_pk = nullptr;
+    long wpkf_off[YOLO2_N_CONV], biasf32_off[YOLO2_N_CONV];
+    struct FTensor {
+        y2::ActGeom g;
+        float4 *d = nullptr;
+    };
+    int f32_batch = 0;
+    FTensor f_in, f_out[32], f_cat;
+    ConvPlan fp32_plan[32];
+    long wh_off[YOLO2_N_CONV], biasf_off[YOLO2_N_CONV];
+    int f16_batch = 0;
+    HalfTensor h_in, h_out[32], h_cat;
+    // per-layer device timing: a ring of event sets, one per profiled run (hipEvents on the
+    // stream the kernels are launched on); the analogue of yolo2_inference.c:75-142
+    static constexpr int kProfSlots = 32;
+    bool prof = false;
+    hipEvent_t ev[kProfSlots][33];
+    bool ev_made = false;
+    long prof_runs = 0;
+};
+
+// ---------------------------------------------------------------------------- helpers that cross translation units
+
+// yolo2_hip.hip
+void y2_free_activations(yolo2_hip_ctx *c);
+void y2_free_f16_activations(yolo2_hip_ctx *c);
+void y2_free_f32_activations(yolo2_hip_ctx *c);
+void y2_destroy_lanes(yolo2_hip_ctx *c);
+int y2_ensure_prof_events(yolo2_hip_ctx *c);
+int y2_ensure(void **p, size_t *cap, size_t need);   // grow-only device scratch
+
+// yolo2_fp16.hip
+void y2_f16_plan_free(yolo2_hip_ctx *c);
+
+// The per-layer driver calls' device work (yolo2_driver.hip validates, latches the register file, takes the lock, binds the
+// device, and synchronises with the reference's timeout semantics afterwards; these only enqueue on the null stream).
+// yolo2_int16.hip:
+int y2_drv_conv_i16(const short *in, short *out, const short *w, const short *beta, int ifm, int ofm, int ksize, int kstride,
+                    int iw, int ih, int ow, int oh, int pad, int is_nl, int qw, int qa_in, int qa_out, int qb, int *path_out);
+void y2_drv_pool_i16(const short *in, short *out, int channels, int ksize, int kstride, int iw, int ih, int ow, int oh);
+void y2_drv_release_i16(void);   // frees the grow-only scratch of y2_drv_conv_i16 (yolo2_accel_cleanup)
+// yolo2_fp32.hip:
+void y2_drv_conv_f32(const float *in, float *out, const float *w, const float *beta, int ifm, int ofm, int ksize, int kstride, int iw,
+                     int ih, int ow, int oh, int pad, int is_nl);

@@ -1,0 +1,598 @@
+// yolo2_fp16.hip -- the fp16 MFMA path of libyolo2_hip.so (config C4): the floating-point form of the same network as
+// implicit-GEMM convolutions on the matrix cores (csrc/kernels_f16.hpp).  Weight packing (also keeps the fp32 blobs resident
+// for yolo2_fp32.hip), the per-context launch table and yolo2_hip_run_batch_fp16.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "y2_internal.hpp"
+#include "kernels_f16.hpp"
+
+using namespace y2;
+
+// ---------------------------------------------------------------------------- the launch table
+//
+// Which kernel runs which layer is decided ONCE per (context, batch) and stored as a table of steps; a pass is a walk over
+// that table (no environment look-ups, no selection logic on the launch path).  The A/B switches of the kernel families
+// (YOLO2_F16_*: tests and tools/abenv.sh use them) are read once, when the weights are loaded, into F16Switches.
+
+struct F16Switches {
+    int lanes = 2;            // YOLO2_F16_LANES=n (1..8), YOLO2_F16_NO_LANES -> 1
+    bool no_mfma0 = false, no_glds = false, no_poolfuse = false, no_halo = false, no_persist = false, persist_all = false;
+    bool ring_all = false, no_ring = false, no_c32 = false, m16 = false, w8 = false, no_wide = false;
+    int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
+    static F16Switches from_env()
+    {
+        F16Switches s;
+        auto on = [](const char *n) { return getenv(n) != nullptr; };
+        if (const char *e = getenv("YOLO2_F16_LANES")) s.lanes = std::max(1, std::min(8, atoi(e)));
+        if (on("YOLO2_F16_NO_LANES")) s.lanes = 1;
+        s.no_mfma0 = on("YOLO2_F16_NO_MFMA0"); s.no_glds = on("YOLO2_F16_NO_GLDS"); s.no_poolfuse = on("YOLO2_F16_NO_POOLFUSE");
+        s.no_halo = on("YOLO2_F16_NO_HALO"); s.no_persist = on("YOLO2_F16_NO_PERSIST"); s.persist_all = on("YOLO2_F16_PERSIST_ALL");
+        s.ring_all = on("YOLO2_F16_RING_ALL"); s.no_ring = on("YOLO2_F16_NO_RING"); s.no_c32 = on("YOLO2_F16_NO_C32");
+        s.m16 = on("YOLO2_F16_M16"); s.w8 = on("YOLO2_F16_W8"); s.no_wide = on("YOLO2_F16_NO_WIDE");
+        if (const char *e = getenv("YOLO2_STAMP_LAYER")) s.stamp_layer = atoi(e);
+        return s;
+    }
+};
+
+struct F16Step;
+typedef void (*F16Launch)(const F16Step &, const float *frames, float *region, hipStream_t);
+
+// How a kernel family stores its output (what the extent check below needs to know about it)
+enum F16Store {
+    FS_FULL = 0,       // full-resolution items at the conv's own geometry (a.PL / a.Wp); IGNORES a.pool
+    FS_FULL_OR_POOL,   // honours a.pool: pooled items at (a.oPL / a.oWp) when set, full-resolution otherwise
+    FS_POOL_ONLY,      // always stores the pooled tensor (fused conv + pool kernels)
+    FS_REGION,         // dense fp32 [B][N][H][W] into the caller's region buffer (extent = the caller's contract)
+};
+
+struct F16Step {
+    int layer = 0;               // network layer whose hipEvent slot this launch is booked to
+    const char *kernel = "";
+    F16Launch launch = nullptr;
+    F16Store store = FS_FULL;
+    ConvF16Args a;
+    dim3 grid, block;
+    unsigned lds = 0;
+    int lt_rows = 0, T = 0;      // extra kernel arguments (halo tile rows, persistent kernels' tile count)
+    const _Float16 *in = nullptr, *w = nullptr;
+    const float *bias = nullptr, *w0 = nullptr;
+    _Float16 *out = nullptr;
+    int B = 0;
+    // pool / reorg steps: source and destination geometry
+    int iCp = 0, iWp = 0, iPL = 0, oCp = 0, oWp = 0, oPL = 0, OH = 0, OW = 0;
+};
+
+struct F16Plan {
+    F16Switches sw;
+    int batch = 0;               // the batch the table below was built for (0 = none)
+    std::vector<F16Step> steps;
+};
+
+void y2_f16_plan_free(yolo2_hip_ctx *c)
+{
+    delete c->f16_plan;
+    c->f16_plan = nullptr;
+}
+
+// The launch-time extent check.  Every step that stores into one of the context's tensors must (a) address it with that
+// tensor's own pitches, (b) cover no more pixels than it holds and (c) stay inside its item.  In round 2 a kernel that ignores
+// ConvF16Args::pool (the persistent halo kernel) was, for one commit, routed to layer 6 while the layer's pooled tensor was
+// passed as its output: full-resolution offsets (104 x 104 planes) into a 52 x 52 tensor = an out-of-bounds store, a GPU memory
+// fault and an abort inside run_batch_fp16.  This check turns that class of mistake into YOLO2_ERROR before
+// anything is launched; yolo2_hip_f16_store_check exposes it so that it can be tested without a GPU.
+static int f16_store_check(const char *kernel, int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store,
+                           int oWp, int oPL, int npix, int npool, int dst_B, int dst_H, int dst_W, int dst_Cp)
+{
+    if (store == FS_REGION) return YOLO2_SUCCESS;
+    const bool pooled = store == FS_POOL_ONLY || (store == FS_FULL_OR_POOL && pool);
+    if (store == FS_FULL && pool)
+        return fail(YOLO2_ERROR, "fp16 plan: %s stores the full-resolution tensor and cannot fuse the pool (ConvF16Args::pool is set)", kernel);
+    const int sH = pooled ? H / 2 : H, sW = pooled ? W / 2 : W;           // geometry the kernel's stores follow
+    const int sWp = pooled ? oWp : W + 1, sPL = pooled ? oPL : (H + 1) * (W + 1), sN = pooled ? npool : npix;
+    if (dst_B != B || dst_H != sH || dst_W != sW)
+        return fail(YOLO2_ERROR, "fp16 plan: %s would store %d x %d x %d pixels into a tensor of %d x %d x %d", kernel, B, sH, sW, dst_B, dst_H, dst_W);
+    if (sWp != dst_W + 1 || sPL != (dst_H + 1) * (dst_W + 1) || sN != dst_B * dst_H * dst_W)
+        return fail(YOLO2_ERROR, "fp16 plan: %s addresses its output with pitch %d / plane %d / %d pixels, the tensor has %d / %d / %d", kernel,
+                    sWp, sPL, sN, dst_W + 1, (dst_H + 1) * (dst_W + 1), dst_B * dst_H * dst_W);
+    if (Cp_out != dst_Cp || out_ch_off < 0 || n_store < 0 || out_ch_off + n_store > dst_Cp)
+        return fail(YOLO2_ERROR, "fp16 plan: %s stores channels [%d, %d) of %d-channel items into %d-channel items", kernel, out_ch_off,
+                    out_ch_off + n_store, Cp_out, dst_Cp);
+    return YOLO2_SUCCESS;
+}
+
+// Test hook (no GPU needed): the check above on explicit numbers.  store: 0 full-resolution only, 1 full or pooled
+// (honours `pool`), 2 pooled only.  Returns YOLO2_SUCCESS or YOLO2_ERROR with yolo2_hip_last_error() set.
+extern "C" int yolo2_hip_f16_store_check(int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store, int dst_B,
+                                         int dst_H, int dst_W, int dst_Cp)
+{
+    if (store < 0 || store > 2) return fail(YOLO2_ERROR, "bad store kind %d", store);
+    return f16_store_check("kernel", store, pool, B, H, W, Cp_out, out_ch_off, n_store, W / 2 + 1, (H / 2 + 1) * (W / 2 + 1), B * H * W,
+                           B * (H / 2) * (W / 2), dst_B, dst_H, dst_W, dst_Cp);
+}
+
+
+static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind);
+
+extern "C" int yolo2_hip_load_weights_fp32(yolo2_hip_ctx *c, const float *weights_reorg, size_t n_weights,
+                                           const float *bias, size_t n_bias)
+{
+    return load_fp32_common(c, weights_reorg, n_weights, bias, n_bias, hipMemcpyHostToDevice);
+}
+
+extern "C" int yolo2_hip_load_weights_fp32_dev(yolo2_hip_ctx *c, uint64_t weights_reorg_dev, size_t n_weights, uint64_t bias_dev,
+                                               size_t n_bias)
+{
+    return load_fp32_common(c, (const void *)(uintptr_t)weights_reorg_dev, n_weights, (const void *)(uintptr_t)bias_dev, n_bias,
+                            hipMemcpyDeviceToDevice);
+}
+
+static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind)
+{
+    if (!c || !weights_reorg || !bias) return fail(YOLO2_ERROR, "null argument");
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    long wtot = 0, btot = 0;
+    int ord = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            const LayerDesc &l = kNet[i];
+            const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN);
+            c->wh_off[ord] = wtot;
+            c->biasf_off[ord] = btot;
+            wtot += i == 0 ? (long)npad * 32 : (long)npad * l.size * l.size * round_up(l.c, 32);
+            btot += npad;
+            ord++;
+        }
+    for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);   // they alias the buffers that are about to be replaced
+    c->f16_lanes.clear();
+    y2_f16_plan_free(c);
+    c->f16_plan = new (std::nothrow) F16Plan();
+    if (!c->f16_plan) return fail(YOLO2_ERROR, "out of host memory");
+    c->f16_plan->sw = F16Switches::from_env();   // the ONLY place the fp16 path reads its switches
+    if (c->wh) (void)hipFree(c->wh);
+    if (c->biasf) (void)hipFree(c->biasf);
+    c->wh = nullptr;
+    c->biasf = nullptr;
+    float *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->wh, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&c->biasf, (size_t)btot * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, kind), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, kind), YOLO2_DMA_ERROR);
+    long woff = 0, boff = 0;
+    ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type != L_CONV) continue;
+        const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN), KK = l.size * l.size;
+        const int Cp = i == 0 ? 32 : round_up(l.c, 32);
+        const long n = (long)npad * (i == 0 ? 1 : KK) * Cp;
+        hipLaunchKernelGGL(k_pack_weights_f16, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
+                           c->wh + c->wh_off[ord], c->biasf + c->biasf_off[ord], bd + boff, l.c, l.n, KK, Cp, npad, i == 0 ? 1 : 0);
+        woff += yolo2_weight_len[ord];
+        boff += yolo2_bias_len[ord];
+        ord++;
+    }
+    // the halo-tile kernels use up to the whole 160 KiB of LDS: raise their dynamic-LDS limit on THIS device
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
+    hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+    // the fp32 blobs stay resident (204 MB of 288 GB): yolo2_hip_run_frame_fp32_host consumes them as they are
+    if (c->wpkf) (void)hipFree(c->wpkf);         // the tiled fp32 path re-packs from the new blobs at its next run
+    if (c->biasf32_pk) (void)hipFree(c->biasf32_pk);
+    c->wpkf = c->biasf32_pk = nullptr;
+    if (c->wf32) (void)hipFree(c->wf32);
+    if (c->bf32) (void)hipFree(c->bf32);
+    c->wf32 = wd;
+    c->bf32 = bd;
+    c->f16_loaded = true;
+    return YOLO2_SUCCESS;
+}
+
+static int alloc_half(yolo2_hip_ctx::HalfTensor &t, int C, int Cp, int H, int W, int B)
+{
+    t.C = C; t.Cp = Cp; t.H = H; t.W = W; t.Wp = W + 1; t.PL = (H + 1) * t.Wp; t.B = B;
+    t.items = (size_t)kLead + (size_t)B * t.PL + kTail;
+    HIP_TRY(hipMalloc((void **)&t.d, t.items * Cp * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(t.d, 0, t.items * Cp * 2), YOLO2_DMA_ERROR);  // zeros = conv padding and channel padding
+    return YOLO2_SUCCESS;
+}
+
+static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
+{
+    if (c->f16_batch == B) return YOLO2_SUCCESS;
+    y2_free_f16_activations(c);
+    if (c->f16_plan) { c->f16_plan->batch = 0; c->f16_plan->steps.clear(); }   // the table points into the tensors just freed
+    int rc;
+    if ((rc = alloc_half(c->h_cat, 1280, 1280, 13, 13, B))) return rc;
+    for (int i = 1; i < 30; ++i) {   // layer 0's 416x416x32 tensor never exists: conv0+pool are fused
+        const LayerDesc &l = kNet[i];
+        if (l.type == L_CONV && i != 24) {
+            if ((rc = alloc_half(c->h_out[i], l.n, round_up(l.n, 32), l.h, l.w, B))) return rc;
+        } else if (l.type == L_MAX) {
+            if ((rc = alloc_half(c->h_out[i], l.c, round_up(l.c, 32), l.h / 2, l.w / 2, B))) return rc;
+        }
+    }
+    c->h_out[24] = c->h_cat;
+    c->h_out[27] = c->h_cat;
+    c->f16_batch = B;
+    // the zero fills above run on the null stream; the pass may be enqueued on a non-blocking stream (the lanes'
+    // are), which does not order itself behind it
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+// ---- launchers: one per kernel instantiation, all with the table's signature
+#define Y2_LAUNCHER(name, ...)                                                                         \
+    static void name(const F16Step &s, const float *frames, float *region, hipStream_t st)           \
+    {                                                                                                  \
+        (void)frames; (void)region;                                                                    \
+        __VA_ARGS__;                                                                                   \
+    }
+Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL))
+Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
+template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
+                                                            s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
+Y2_LAUNCHER(L_c32_pool, hipLaunchKernelGGL(k_conv_f16_c32_pool, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.T))
+template <int BN> Y2_LAUNCHER(L_glds, hipLaunchKernelGGL((k_conv_f16_glds<BN>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
+                                                            s.store == FS_REGION ? region : (float *)nullptr, s.a))
+template <int BN, int BK> Y2_LAUNCHER(L_reg, hipLaunchKernelGGL((k_conv_f16<128, BN, BK>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
+                                                                   s.store == FS_REGION ? region : (float *)nullptr, s.a))
+template <int BN, int NW, int TS> Y2_LAUNCHER(L_halo_p, hipLaunchKernelGGL((k_conv_f16_halo_p<BN, NW, TS>), s.grid, s.block, s.lds, st, s.in, s.w,
+                                                                            s.bias, s.out, s.a, s.lt_rows, s.T))
+template <int BN, int NB, int NW, int TS> Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS>), s.grid, s.block, s.lds, st, s.in,
+                                                                                  s.w, s.bias, s.out, s.a, s.lt_rows))
+Y2_LAUNCHER(L_maxpool, hipLaunchKernelGGL(k_maxpool2_f16, s.grid, s.block, 0, st, s.in, s.out, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
+Y2_LAUNCHER(L_reorg, hipLaunchKernelGGL(k_reorg_f16, s.grid, s.block, 0, st, s.in, s.out, s.B, s.iCp, s.iWp, s.iPL, s.oCp, s.oWp, s.oPL))
+#undef Y2_LAUNCHER
+
+// Builds the table for batch B (the tensors exist: ensure_f16_batch).  The selection rules are those measured in rounds 1-2
+// (DESIGN.md 4.3); every conv step passes f16_store_check against the tensor it is handed before it enters the table.
+static int build_f16_plan(yolo2_hip_ctx *c, int B)
+{
+    F16Plan &P = *c->f16_plan;
+    const F16Switches &sw = P.sw;
+    P.steps.clear();
+    P.batch = 0;
+    typedef yolo2_hip_ctx::HalfTensor HT;
+    auto checked_push = [&](F16Step &s, const HT &dst) -> int {
+        const int rc = f16_store_check(s.kernel, s.store, s.a.pool, B, s.a.H, s.a.W, s.a.Cp_out, s.a.out_ch_off, s.a.n_store, s.a.oWp, s.a.oPL,
+                                       s.a.npix, s.a.npool, dst.B, dst.H, dst.W, dst.Cp);
+        if (rc) return rc;
+        P.steps.push_back(s);
+        return YOLO2_SUCCESS;
+    };
+    {   // layers 0+1 fused: conv 3->32 + leaky + 2x2 pool straight from the float frames
+        const HT &g = c->h_out[1];
+        F16Step s;
+        s.layer = 0; s.B = B;   // (booked to layer 0; the pool, layer 1, has no launch of its own)
+        s.w0 = c->w0f; s.bias = c->w0f + 27 * 32; s.out = g.d; s.oWp = g.Wp; s.oPL = g.PL;
+        s.block = dim3(256);
+        if (!sw.no_mfma0) {   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
+            s.kernel = "k_conv0_pool_mfma"; s.launch = L_conv0_mfma;
+            s.grid = dim3((unsigned)B * (416 / 16) * (416 / 32));
+        } else {
+            s.kernel = "k_conv0_pool_f16"; s.launch = L_conv0_valu;
+            s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
+        }
+        if (g.B != B || g.H != 208 || g.W != 208 || g.Cp != 32) return fail(YOLO2_ERROR, "fp16 plan: layer-1 tensor has the wrong geometry");
+        P.steps.push_back(s);
+    }
+    int ord = 1, skip_pool = -1;
+    const HT *cur = &c->h_out[1];
+    for (int i = 2; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        switch (l.type) {
+        case L_CONV: {
+            const HT *tin = i == 26 ? &c->h_out[16] : (i == 29 ? &c->h_cat : cur);
+            const HT &tout = c->h_out[i];
+            F16Step s;
+            s.layer = i; s.B = B;
+            ConvF16Args &a = s.a;
+            a.B = B; a.H = l.h; a.W = l.w; a.Wp = l.w + 1; a.PL = (l.h + 1) * (l.w + 1);
+            a.Cp_in = tin->Cp;
+            a.Cp_out = i == 30 ? 0 : tout.Cp;
+            a.N = l.n;
+            a.out_ch_off = i == 24 ? 256 : 0;
+            a.n_store = i == 30 ? l.n : round_up(l.n, 32);
+            a.npix = B * l.h * l.w;
+            a.leaky = l.leaky;
+            a.KS = l.size;
+            a.pool = 0; a.oWp = a.oPL = a.npool = 0;
+            a.n_tiles = 1;
+            set_fast_div(a);
+            a.stamp = sw.stamp_layer == i;
+            s.w = (const _Float16 *)(c->wh + c->wh_off[ord]);
+            s.bias = (const float *)(c->biasf + c->biasf_off[ord]);
+            s.in = (const _Float16 *)tin->d;
+            s.out = i == 30 ? (_Float16 *)nullptr : tout.d;
+            s.store = i == 30 ? FS_REGION : FS_FULL_OR_POOL;
+            const HT *dst = &tout;
+            ord++;
+            const bool bk64 = a.Cp_in % 64 == 0;   // K-step of 64 channels wherever the item size allows it
+            const bool glds = bk64 && !sw.no_glds;   // LDS-DMA staging wherever the K-step is 64
+            // Conv layers whose only consumer is the 2x2 pool after them (2 and 6; 10 runs the halo kernel, 16 also
+            // feeds the route) store the pooled tensor directly: MFMA rows ordered by pool window, max in the epilogue.
+            // The persistent halo kernel takes the 104x104 layers EXCEPT layer 6: it stores the full-resolution tensor only
+            // (FS_FULL), and the pool kernel that then has to follow (0.08 ms at batch 128) costs more than the conv gains.
+            const bool pool_next = kNet[i + 1].type == L_MAX && !sw.no_poolfuse;
+            const bool persist_ok = !sw.no_glds && !sw.no_halo && !sw.no_persist && ((l.w > 52 && !(i == 6 && pool_next)) || sw.persist_all);
+            const bool fuse_pool = (i == 2 || (i == 6 && !persist_ok)) && pool_next;
+            if (fuse_pool) {
+                const HT &tp = c->h_out[i + 1];
+                a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
+                a.Cp_out = tp.Cp;
+                s.out = tp.d;
+                dst = &tp;
+                skip_pool = i + 1;
+            }
+            const bool in32 = ((size_t)kLead + (size_t)B * a.PL) * a.Cp_in * 2 < (1ull << 32);   // 32-bit byte offsets into the input
+            int rc = YOLO2_SUCCESS;
+            bool done = false;
+            // 1x1 layers: persistent workgroups over a ring of staged K-steps (k_gemm1_f16_p)
+            if (!done && l.size == 1 && bk64 && (i == 30 || sw.ring_all) && in32 && !sw.no_ring) {
+                const int bn = l.n <= 64 ? 64 : 128;
+                a.n_tiles = round_up(l.n, bn) / bn;
+                s.T = ((a.npix + 255) / 256) * a.n_tiles;
+                const int rounds = (s.T + 255) / 256;                                    // tiles per workgroup
+                s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8))));
+                if (bn == 64) { s.kernel = "k_gemm1_f16_p<256,64,3>"; s.launch = L_ring<64>; s.block = dim3(256); s.lds = 3 * (256 + 64) * 128; }
+                else { s.kernel = "k_gemm1_f16_p<256,128,3>"; s.launch = L_ring<128>; s.block = dim3(512); s.lds = 3 * (256 + 128) * 128; }
+                if (s.store != FS_REGION) s.store = FS_FULL;
+                done = true;
+            }
+            // the 32-channel layer + its pool: 16 x 16 tiles, patch and all nine taps' weights resident in LDS (k_conv_f16_c32_pool)
+            if (!done && fuse_pool && a.Cp_in == 32 && l.size == 3 && l.n == 64 && l.h % 16 == 0 && l.w % 16 == 0 && a.Cp_out >= 64 &&
+                ((size_t)kLead + (size_t)B * a.PL) * 64 < (1ull << 32) && !sw.no_c32) {
+                s.T = B * (l.h / 16) * (l.w / 16);
+                s.kernel = "k_conv_f16_c32_pool"; s.launch = L_c32_pool; s.store = FS_POOL_ONLY;
+                s.grid = dim3((unsigned)std::min(s.T, 512)); s.block = dim3(256); s.lds = (9 * 64 + 336) * 64;   // two workgroups per CU, weights staged once each
+                done = true;
+            }
+            const int m_tiles = fuse_pool ? (a.npool + 31) / 32 : (a.npix + 127) / 128;   // 128-row tiles (32 pool windows)
+            if (!done && l.n <= 64) {
+                a.n_tiles = round_up(l.n, 64) / 64;
+                s.grid = dim3(m_tiles * a.n_tiles); s.block = dim3(256);
+                if (glds) { s.kernel = "k_conv_f16_glds<64>"; s.launch = L_glds<64>; }
+                else if (bk64) { s.kernel = "k_conv_f16<128,64,64>"; s.launch = L_reg<64, 64>; }
+                else { s.kernel = "k_conv_f16<128,64,32>"; s.launch = L_reg<64, 32>; }
+                done = true;
+            }
+            if (!done) {
+                a.n_tiles = round_up(l.n, kBN) / kBN;
+                // dense halo tile: 256 pixels + W+1 on either side, rounded to 8-row groups, + 8 zero rows
+                const int lt_rows = round_up(256 + 2 * (l.w + 1), 8) + 8;
+                const size_t a_bytes = (size_t)2 * lt_rows * 128, cap = 160 * 1024;
+                // persistent halo-tile kernel: the workgroup walks its tiles, the next tile's staging overlaps this one's tail
+                if (glds && l.size == 3 && l.n % kBN == 0 && persist_ok && !fuse_pool) {
+                    const bool off32 = ((size_t)kLead + (size_t)B * a.PL) * std::max(a.Cp_in, a.Cp_out) * 2 < (1ull << 32);
+                    const bool wide = l.n % 256 == 0 && a_bytes + (size_t)2 * 256 * 128 <= cap;
+                    const int bn = wide ? 256 : 128;
+                    const size_t lds = a_bytes + (size_t)2 * bn * 128;
+                    if (off32 && lds <= cap && lt_rows - 8 <= 8 * 8 * 8) {
+                        a.n_tiles = l.n / bn;
+                        s.T = ((a.npix + 255) / 256) * a.n_tiles;
+                        const int rounds = (s.T + 255) / 256;
+                        // (Launched with one tile per workgroup - the same kernel, only the LDS-free epilogue and the operand order
+                        //  differ from k_conv_f16_halo - it measured 2.8 % slower over the pass at batch 256.)
+                        s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8))));
+                        s.lds = (unsigned)lds; s.lt_rows = lt_rows; s.store = FS_FULL;
+                        if (wide && sw.m16) { s.kernel = "k_conv_f16_halo_p<256,16,16>"; s.launch = L_halo_p<256, 16, 16>; s.block = dim3(1024); }
+                        else if (wide) { s.kernel = "k_conv_f16_halo_p<256,16,32>"; s.launch = L_halo_p<256, 16, 32>; s.block = dim3(1024); }
+                        else if (sw.m16) { s.kernel = "k_conv_f16_halo_p<128,8,16>"; s.launch = L_halo_p<128, 8, 16>; s.block = dim3(512); }
+                        else { s.kernel = "k_conv_f16_halo_p<128,8,32>"; s.launch = L_halo_p<128, 8, 32>; s.block = dim3(512); }
+                        done = true;
+                    }
+                }
+                // 3x3 layers: halo-tile kernel (input tile staged once per 64-channel chunk, nine taps read it
+                // shifted) wherever its LDS arena fits: 2 x lt_rows x 128 B (A) + NB x BN x 128 B (B) + fo table
+                if (!done && glds && l.size == 3 && l.n % kBN == 0 && !sw.no_halo && !fuse_pool) {
+                    const size_t fo_bytes = 256 * sizeof(int);
+                    const size_t lds256 = a_bytes + (size_t)2 * 256 * 128 + fo_bytes, lds128 = a_bytes + (size_t)3 * 128 * 128 + fo_bytes;
+                    const bool wide = l.n % 256 == 0 && lds256 <= cap && a_bytes + (size_t)2 * 256 * 128 >= (size_t)256 * 264 * 2 && !sw.no_wide;
+                    const bool three = lds128 <= cap;
+                    // (the two-buffer 256x128 form that would fit the 104x104 layers runs one workgroup per CU and measured
+                    //  6 % slower there than the 128x128 kernel with two: only the shapes below are used)
+                    const bool fits = lt_rows - 8 <= 8 * 8 * 8 && a_bytes >= (size_t)256 * kCtRow * 2 && (wide || three) && in32;
+                    if (fits) {   // (the kernels' dynamic-LDS limit was raised for this device in load_weights_fp32)
+                        s.lt_rows = lt_rows; s.store = FS_FULL;
+                        if (wide) {
+                            a.n_tiles = l.n / 256;
+                            s.grid = dim3(((a.npix + 255) / 256) * a.n_tiles); s.lds = (unsigned)lds256;
+                            if (sw.m16) { s.kernel = "k_conv_f16_halo<256,2,16,16>"; s.launch = L_halo<256, 2, 16, 16>; s.block = dim3(1024); }
+                            else if (!sw.w8) { s.kernel = "k_conv_f16_halo<256,2,16>"; s.launch = L_halo<256, 2, 16, 32>; s.block = dim3(1024); }   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
+                            else { s.kernel = "k_conv_f16_halo<256,2>"; s.launch = L_halo<256, 2, 8, 32>; s.block = dim3(512); }
+                        } else {   // `fits` without `wide` implies `three`
+                            s.grid = dim3(((a.npix + 255) / 256) * a.n_tiles); s.lds = (unsigned)lds128;
+                            s.kernel = "k_conv_f16_halo<128,3>"; s.launch = L_halo<128, 3, 8, 32>; s.block = dim3(512);
+                        }
+                        done = true;
+                    }
+                }
+                // (a 256x128 tile with 8 wavefronts and per-tap A staging was measured 8 % SLOWER than 128x128
+                //  with two workgroups per CU: without the halo reuse the bigger tile only adds barrier cost)
+                if (!done) {
+                    s.grid = dim3(m_tiles * a.n_tiles); s.block = dim3(256);
+                    if (glds) { s.kernel = "k_conv_f16_glds<128>"; s.launch = L_glds<128>; }
+                    else if (bk64) { s.kernel = "k_conv_f16<128,128,64>"; s.launch = L_reg<128, 64>; }
+                    else { s.kernel = "k_conv_f16<128,128,32>"; s.launch = L_reg<128, 32>; }
+                    done = true;
+                }
+            }
+            if ((rc = checked_push(s, *dst))) return rc;
+            if (i != 30) cur = dst;
+            break;
+        }
+        case L_MAX: {
+            if (i == skip_pool) { cur = &c->h_out[i]; break; }   // already produced by the conv before it
+            const HT &gi = *cur, &go = c->h_out[i];
+            if (gi.B != B || go.B != B || gi.H != 2 * go.H || gi.W != 2 * go.W || gi.Cp != go.Cp)
+                return fail(YOLO2_ERROR, "fp16 plan: pool layer %d: %d x %d x %d -> %d x %d x %d does not halve", i, gi.H, gi.W, gi.Cp, go.H, go.W, go.Cp);
+            F16Step s;
+            s.layer = i; s.B = B; s.kernel = "k_maxpool2_f16"; s.launch = L_maxpool;
+            s.in = gi.d; s.out = go.d; s.oCp = go.Cp; s.OH = go.H; s.OW = go.W; s.iWp = gi.Wp; s.iPL = gi.PL; s.oWp = go.Wp; s.oPL = go.PL;
+            s.grid = dim3(blocks_for((long)B * go.H * go.W * (go.Cp / 8), 256)); s.block = dim3(256);
+            P.steps.push_back(s);
+            cur = &c->h_out[i];
+            break;
+        }
+        case L_REORG: {
+            const HT &gi = *cur, &go = c->h_cat;
+            if (gi.B != B || go.B != B || gi.H != 26 || gi.W != 26 || gi.Cp < 64 || go.H != 13 || go.W != 13 || go.Cp < 256)
+                return fail(YOLO2_ERROR, "fp16 plan: reorg layer %d has the wrong geometry", i);
+            F16Step s;
+            s.layer = i; s.B = B; s.kernel = "k_reorg_f16"; s.launch = L_reorg;
+            s.in = gi.d; s.out = go.d; s.iCp = gi.Cp; s.iWp = gi.Wp; s.iPL = gi.PL; s.oCp = go.Cp; s.oWp = go.Wp; s.oPL = go.PL;
+            s.grid = dim3(blocks_for((long)B * 256 * 169, 256)); s.block = dim3(256);
+            P.steps.push_back(s);
+            cur = &c->h_cat;
+            break;
+        }
+        default:
+            break;  // route: concat by placement; region: the last conv already wrote the dense fp32 tensor
+        }
+    }
+    P.batch = B;
+    if (getenv("YOLO2_VERBOSE"))   // (plan construction, not the launch path)
+        for (const F16Step &s : P.steps)
+            fprintf(stderr, "[yolo2_hip] fp16 plan B=%d L%-2d %-30s grid %u block %u lds %u\n", B, s.layer, s.kernel, s.grid.x, s.block.x, s.lds);
+    return YOLO2_SUCCESS;
+}
+
+// Kernel chosen for layer `layer_idx` by the current fp16 plan (after the first run_batch_fp16 at this batch); "" if none.
+extern "C" const char *yolo2_hip_fp16_layer_kernel(yolo2_hip_ctx *c, int layer_idx)
+{
+    if (!c) return "";
+    if (!c->f16_lanes.empty()) c = c->f16_lanes[0];
+    if (!c->f16_plan) return "";
+    for (const F16Step &s : c->f16_plan->steps)
+        if (s.layer == layer_idx) return s.kernel;
+    return "";
+}
+
+static int make_f16_lanes(yolo2_hip_ctx *c, int want_lanes)
+{
+    for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);
+    c->f16_lanes.clear();
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
+    std::vector<yolo2_hip_ctx *> made;   // committed only when all lanes are complete
+    bool ok = true;
+    for (int i = 0; i < want_lanes && ok; ++i) {
+        yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
+        if (!l) { ok = false; break; }
+        made.push_back(l);
+        l->device = c->device;
+        l->is_lane = true;
+        l->wh = c->wh; l->biasf = c->biasf; l->w0f = c->w0f;
+        memcpy(l->wh_off, c->wh_off, sizeof(c->wh_off));
+        memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
+        l->f16_loaded = true;
+        l->f16_plan = new (std::nothrow) F16Plan();
+        ok = l->f16_plan && hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess;
+        if (ok) l->f16_plan->sw = c->f16_plan->sw;   // a lane runs the parent's kernel selection
+    }
+    if (!ok) {
+        for (yolo2_hip_ctx *l : made) yolo2_hip_destroy(l);
+        return fail(YOLO2_ERROR, "fp16 lanes: context / stream / event creation failed");
+    }
+    c->f16_lanes = made;
+    if (c->prof) (void)yolo2_hip_set_profiling(c->f16_lanes[0], 1);
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, int batch, uint64_t region_dev, void *stream)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!c->f16_loaded || !c->f16_plan) return fail(YOLO2_ERROR, "fp32 weights not loaded (yolo2_hip_load_weights_fp32)");
+    if (!frames_dev || !region_dev) return fail(YOLO2_ERROR, "null buffer address");
+    if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    hipStream_t st = (hipStream_t)stream;
+    // Two half-batch lanes like the int16 path: the big-tile kernels run one workgroup per CU and a layer is only
+    // 2-3 generations of workgroups, so a second stream's launches fill the last, partly empty generation.
+    const int want_lanes = c->f16_plan->sw.lanes;
+    if (!c->is_lane && batch >= 64 && want_lanes > 1 && batch % want_lanes == 0) {
+        if ((int)c->f16_lanes.size() != want_lanes) {
+            const int rc = make_f16_lanes(c, want_lanes);
+            if (rc) return rc;
+        }
+        const int half = batch / want_lanes;
+        HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
+        for (int i = 0; i < want_lanes; ++i) {
+            yolo2_hip_ctx *l = c->f16_lanes[i];
+            HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
+            const int rc = yolo2_hip_run_batch_fp16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
+                                                    region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(float), l->lane_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
+            HIP_TRY(hipStreamWaitEvent(st, l->ev_join, 0), YOLO2_ERROR);
+        }
+        return YOLO2_SUCCESS;
+    }
+    int rc = ensure_f16_batch(c, batch);
+    if (rc) return rc;
+    if (c->f16_plan->batch != batch && (rc = build_f16_plan(c, batch))) return rc;
+    if (c->prof && (rc = y2_ensure_prof_events(c))) return rc;
+    hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
+    // the table walk: hipEvent slot i opens layer i, slot i+1 closes it (layers 0+1 are one launch, booked to layer 0)
+    const float *frames = (const float *)(uintptr_t)frames_dev;
+    float *region = (float *)(uintptr_t)region_dev;
+    int next_ev = 0;
+    for (const F16Step &s : c->f16_plan->steps) {
+        if (ev) for (; next_ev <= s.layer; ++next_ev) (void)hipEventRecord(ev[next_ev], st);   // layers without a launch of their own
+        s.launch(s, frames, region, st);
+        if (ev) { (void)hipEventRecord(ev[s.layer + 1], st); next_ev = s.layer + 2; }
+    }
+    if (ev) for (; next_ev <= 32; ++next_ev) (void)hipEventRecord(ev[next_ev], st);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    if (ev) c->prof_runs++;
+    return YOLO2_SUCCESS;
+}
+
+#ifdef Y2_STAMPS
+// diagnostic build only: the halo kernel's workgroup timeline of the launch selected by YOLO2_STAMP_LAYER
+extern "C" int yolo2_hip_debug_stamps(unsigned long long *dst, int n_wg)
+{
+    if (n_wg > kStampWGs) n_wg = kStampWGs;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(y2_stamps), (size_t)n_wg * 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+extern "C" int yolo2_hip_run_batch_fp16_host(yolo2_hip_ctx *c, const float *frames, int batch, float *region)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    float *fd = nullptr, *rd = nullptr;
+    HIP_TRY(hipMalloc((void **)&fd, (size_t)batch * YOLO2_FRAME_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&rd, (size_t)batch * YOLO2_REGION_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(fd, frames, (size_t)batch * YOLO2_FRAME_ELEMS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    int rc = yolo2_hip_run_batch_fp16(c, (uint64_t)(uintptr_t)fd, batch, (uint64_t)(uintptr_t)rd, nullptr);
+    if (rc == YOLO2_SUCCESS) {
+        hipError_t e = hipMemcpy(region, rd, (size_t)batch * YOLO2_REGION_ELEMS * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(YOLO2_DMA_ERROR, "D2H of region tensor failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(fd);
+    (void)hipFree(rd);
+    return rc;
+}

@@ -1,0 +1,1098 @@
+// yolo2_int16.hip -- the int16 path of libyolo2_hip.so: what yolov2_hls_ps does at Precision::INT16
+// (hls/models/yolov2/yolo2_model.cpp:229-449) as kernel launches on one stream - weight loading and the per-block
+// proof of the arithmetic form, launch planning (tile shapes, XCD grid, conv + pool fusion, split-K), the batch plan
+// (autotune / lanes) and yolo2_hip_run_batch_int16; plus the device work of the driver tier's per-layer int16 calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "y2_internal.hpp"
+#include "kernels_int16.hpp"
+
+using namespace y2;
+
+// ---------------------------------------------------------------------------- launch helpers
+
+struct ShiftSpec {
+    int right, left, mag;
+};
+static ShiftSpec make_shift(int s)  // core_compute.cpp:48-63: magnitude capped at 30
+{
+    ShiftSpec sh;
+    sh.right = s > 0;
+    sh.left = s < 0;
+    int a = sh.right ? s : (sh.left ? -s : 0);
+    sh.mag = a > 30 ? 30 : a;
+    return sh;
+}
+
+// 32-bit exactness: no intermediate of the fast kernel may leave int32.
+//   |p + round| <= maxsum*32768 + round ;  |acc + scaled| <= max(32768,|bias0|) + |p + round|
+// Form B keeps acc*2^s + round in the register:  max(32768,|bias0|)*2^s + round + |p| must fit.
+// Form C packs two int16 accumulators per register and needs every increment to fit int16.
+// Form D is form C with the shift folded into the weights (w * 2^(16-s) must still be int16 and the
+// scaled dot product + 2^15 must fit int32); only offered when the caller passes the block's max |w|.
+// Returns 0 (form A), 1 (form B), 3 (form C), 4 (form D) or 2 (64-bit); the narrowest legal form wins.
+static int choose_path(int so, int sb, int maxsum, int max_abs_bias, int max_abs_w = -1)
+{
+    if (so < 0) return 2;
+    const ShiftSpec o = make_shift(so), b = make_shift(sb);
+    const long long round = o.mag > 0 ? (1LL << (o.mag - 1)) : 0;
+    long long bias0 = max_abs_bias;
+    if (b.right) bias0 = ((bias0 + (b.mag > 0 ? (1LL << (b.mag - 1)) : 0)) >> b.mag) + 1;
+    else if (b.left) bias0 = bias0 << b.mag;
+    const long long accmax = std::max<long long>(32768, bias0);
+    const long long pmax = (long long)maxsum * 32768;
+    if (bias0 > 2147483647LL) return 2;
+    int path = 2;
+    const bool okA = pmax + round + accmax <= 2147483647LL;
+    const bool okB = (accmax << o.mag) + round + pmax <= 2147483647LL;
+    // form C: every t = (p + round) >> s and the shifted bias must fit int16 (and p + round int32)
+    const bool okC = okA && bias0 <= 32767 && ((pmax + round) >> o.mag) <= 32767;
+    const int k = 16 - so;
+    const bool okD = okC && max_abs_w >= 0 && k >= 0 && k <= 15 && ((long long)max_abs_w << k) <= 32767 &&
+                     (((long long)maxsum << k) * 32768 + 32768) <= 2147483647LL;
+    if (okA) path = 0;
+    if (okB) path = 1;
+    if (okC) path = 3;
+    if (okD) path = 4;
+    const char *force = getenv("YOLO2_FORCE_PATH");  // test hook: a narrower path only when it is legal, 2 always
+    if (force) {
+        const int f = atoi(force);
+        if (f == 2 || (f == 0 && okA) || (f == 1 && okB) || (f == 3 && okC) || (f == 4 && okD)) path = f;
+    }
+    return path;
+}
+
+static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long out_base, int CGout, int forceP = 0)
+{
+    const ShiftSpec so = make_shift(p.Qa_in + p.Qw - p.Qa_out), sb = make_shift(p.Qb - p.Qa_out);
+    const int npix = gin.B * gin.H * gin.W;
+    const int maxP = (p.path == 1 || p.path == 3 || p.path == 4) ? 8 : 4;  // form A / 64-bit: 8 pixels per lane overflows the register file
+    if (forceP) {
+        p.P = std::min(forceP, maxP);
+    } else {
+        p.P = maxP;
+        // small problems (single frame): fewer pixels per lane -> more workgroups
+        while (p.P > 1 && (long)((npix + 64 * p.P - 1) / (64 * p.P)) * (p.mb_count ? p.mb_count : (p.N + 31) / 32) < 1024) p.P >>= 1;
+    }
+    const int halo = p.K == 3 ? gin.Wp + 1 : 0;
+    while (p.P > 1 && tile_items_bound(gin, 64 * p.P, halo) > kMaxTileItems) p.P >>= 1;
+    if (p.splitk) {   // splitk = number of K-splits S (4 or 8); 64/S pixels per wavefront
+        if (p.splitk_pp > 1 && !(p.splitk == 4 && p.K == 3 && p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK"))) p.splitk_pp = 1;   // only built for 3x3 form D layers
+        const int S = p.splitk, lt = tile_items_bound(gin, 64 / S * p.splitk_pp, halo);
+        // (8 splits only for 1x1 layers: on the 3x3 layers the kernel is bound by re-staging the weight slices per
+        //  pixel tile, and halving the tile to 8 pixels measured 2x slower)
+        if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
+    }
+    if (p.splitk) p.P = 1;
+    const int T = p.splitk ? 64 / p.splitk * p.splitk_pp : 64 * p.P;
+    ConvArgs &a = p.args;
+    // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
+    a.B = gin.B; a.H = gin.H; a.W = gin.W; a.Wp = gin.Wp; a.PL = gin.PL;
+    a.CGin = gin.CG;
+    a.CGout = CGout;
+    a.npix = npix;
+    set_conv_div(a);
+    a.in_cg_stride = gin.cg_stride;
+    a.out_cg_stride = out_cg_stride;
+    a.out_base = out_base;
+    a.shift = so.mag;
+    a.round = (so.right && so.mag > 0) ? (1 << (so.mag - 1)) : 0;
+    if (p.path == 4) { a.shift = 16; a.round = 32768; }   // form D: these blocks' weights are stored as w * 2^(16-s)
+    a.sh_right = so.right; a.sh_left = so.left;
+    a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
+    a.leaky = p.leaky;
+    a.lt_max = tile_items_bound(gin, T, halo);
+    p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
+    // (two channel groups per barrier for the 3x3 forms C/D - one barrier per 18 taps - was measured: -1 to -2 %)
+    p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32 + 4) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
+    p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
+    // XCD grid over (tiles, blocks): bytes crossing the fabric = input x Xm + weights x Xt x G, where
+    // G > 1 only if the blocks one XCD owns do not keep their weights in its 4 MiB L2 (then every
+    // generation of co-resident tiles fetches them again).  See xcd_partition in kernels_int16.hpp.
+    a.xcd_remap = 0;
+    if (!getenv("YOLO2_NO_XCD_REMAP")) {
+        const double in_bytes = (double)gin.B * gin.CG * gin.PL * 8;
+        const double w_mb = (double)gin.CG * p.K * p.K * 32 * 8;
+        const int gy = (int)p.grid.y, gx = (int)p.grid.x;
+        double best = 0;
+        for (int lg = 0; lg < 4; ++lg) {
+            const int Xm = 1 << lg, Xt = 8 >> lg;
+            if (Xm > gy || Xt > gx) continue;
+            const int own = (gy + Xm - 1) / Xm;
+            double G = 1;
+            if (own * w_mb > 3.0e6) G = std::max(1.0, ((double)gx / Xt) / std::max(1, 128 / own));
+            const double cost = in_bytes * Xm + w_mb * gy * Xt * G;
+            if (!a.xcd_remap || cost < best) { best = cost; a.xcd_remap = 1 + lg; }
+        }
+    }
+}
+
+// Upper bound of the LDS tile (items) of k_conv_i16_pool: 64 consecutive pool windows in raster order.  Between the
+// top-left pixels of two consecutive windows the flat offset grows by 2 (same row pair), W + 4 (next row pair) or
+// 2W + 5 (next frame); the tile adds a halo of Wp + 1 on either side and the bottom-right pixel of its last window.
+static int pool_tile_items_bound(const ActGeom &g)
+{
+    const int OW = g.W / 2, OHW = (g.H / 2) * OW;
+    const int wraps = std::min(63, (63 + OW - 1) / OW), frames = std::min(63, (63 + OHW - 1) / OHW);
+    return 126 + wraps * (g.W + 2) + frames * (g.W + 1) + 3 * g.Wp + 4;
+}
+
+// Re-plans a conv launch (already planned by plan_conv for this input geometry) as the fused conv + pool kernel.
+static bool plan_conv_pool(ConvPlan &p, const ActGeom &gin, const ActGeom &gpool, int full)
+{
+    if (p.K != 3 || (p.path != 3 && p.path != 4) || (gin.H & 1) || (gin.W & 1)) return false;
+    const int lt = pool_tile_items_bound(gin);
+    if (lt > 12 * 256) return false;
+    ConvArgs &a = p.args;
+    p.splitk = 0; p.grp = 1; p.P = 4; p.lds_pad = 0;
+    p.pool_fused = full ? 2 : 1;
+    a.lt_max = lt;
+    a.nwin = gin.B * (gin.H / 2) * (gin.W / 2);
+    a.oWp = gpool.Wp; a.oPL = gpool.PL;
+    a.pool_cg_stride = gpool.cg_stride;
+    a.pool_base = kLead;
+    p.lds_bytes = lt * 8 * (gin.CG > 1 ? 2 : 1);
+    p.grid = dim3((a.nwin + 63) / 64, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
+    return true;
+}
+
+template <int MODE, bool FULL>
+static void launch_conv_pool_n(const ConvPlan &p, const int2 *in, int2 *out, int2 *out_pool, const int2 *wpk, const short *bias,
+                               hipStream_t st)
+{
+    const int nst = (p.args.lt_max + 255) / 256;
+#define Y2_POOL(NSTV, SINGLEV) hipLaunchKernelGGL((k_conv_i16_pool<MODE, NSTV, FULL, SINGLEV>), p.grid, dim3(256), p.lds_bytes, st, in, out, out_pool, wpk, bias, p.args)
+    if (p.args.CGin == 1) {   // layer 0: the whole input tile is staged once, up front
+        if (nst <= 4) Y2_POOL(4, true);
+        else Y2_POOL(12, true);
+    } else if (nst <= 2) Y2_POOL(2, false);
+    else if (nst <= 3) Y2_POOL(3, false);
+    else if (nst <= 5) Y2_POOL(5, false);
+    else if (nst <= 8) Y2_POOL(8, false);
+    else Y2_POOL(12, false);
+#undef Y2_POOL
+}
+
+template <int KS, int MODE, int P>
+static void launch_conv_n(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
+{
+    const int nst = (p.args.lt_max * p.grp + 255) / 256;
+    if (KS == 1 && p.grp == 8 && MODE != 2) {
+        if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 4, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        else hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 8, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        return;
+    }
+    if (nst <= 2) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+    else if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 4>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+    else hipLaunchKernelGGL((k_conv_i16<KS, P, MODE, 8>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+}
+
+template <int KS, int MODE>
+static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias,
+                          hipStream_t st)
+{
+    switch (p.P) {
+    case 8: launch_conv_n<KS, MODE, 8>(p, in, out, wpk, bias, st); break;
+    case 4: launch_conv_n<KS, MODE, 4>(p, in, out, wpk, bias, st); break;
+    case 2: launch_conv_n<KS, MODE, 2>(p, in, out, wpk, bias, st); break;
+    default: launch_conv_n<KS, MODE, 1>(p, in, out, wpk, bias, st); break;
+    }
+}
+
+static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st,
+                        int2 *out_pool = nullptr)
+{
+    if (p.pool_fused) {   // out_pool: the pooled tensor (the layer after this conv)
+        if (p.path == 4) {
+            if (p.pool_fused == 2) launch_conv_pool_n<4, true>(p, in, out, out_pool, wpk, bias, st);
+            else launch_conv_pool_n<4, false>(p, in, out, out_pool, wpk, bias, st);
+        } else {
+            if (p.pool_fused == 2) launch_conv_pool_n<3, true>(p, in, out, out_pool, wpk, bias, st);
+            else launch_conv_pool_n<3, false>(p, in, out, out_pool, wpk, bias, st);
+        }
+        return;
+    }
+    if (p.splitk) {
+        const int nst = (p.splitk * (p.args.lt_max + p.K * p.K * 32) + 255) / 256;
+        const bool pack = p.path == 4 && !getenv("YOLO2_SPLITK_NO_PACK");   // form D layers: packed int16 triples
+#define Y2_SPLITK(KSV, NSTV, PACKV, SV) \
+    hipLaunchKernelGGL((k_conv_i16_splitk<KSV, NSTV, PACKV, SV>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args)
+#define Y2_SPLITK_S(KSV, NSTV, PACKV) do { if (p.splitk == 8) Y2_SPLITK(KSV, NSTV, PACKV, 8); else Y2_SPLITK(KSV, NSTV, PACKV, 4); } while (0)
+        if (pack) {
+            if (p.K == 3 && p.splitk_pp == 4) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 4>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else if (p.K == 3 && p.splitk_pp == 2) hipLaunchKernelGGL((k_conv_i16_splitk<3, 8, true, 4, 2>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+            else if (p.K == 3) Y2_SPLITK(3, 8, true, 4);
+            else if (nst <= 2) Y2_SPLITK_S(1, 2, true);
+            else Y2_SPLITK_S(1, 8, true);
+        } else {
+            if (p.K == 3) Y2_SPLITK(3, 8, false, 4);
+            else if (nst <= 2) Y2_SPLITK_S(1, 2, false);
+            else Y2_SPLITK_S(1, 8, false);
+        }
+#undef Y2_SPLITK_S
+#undef Y2_SPLITK
+        return;
+    }
+    if (p.K == 3) {
+        if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4) launch_conv_p<3, 4>(p, in, out, wpk, bias, st);
+        else if (p.path == 3) launch_conv_p<3, 3>(p, in, out, wpk, bias, st);
+        else if (p.path == 1) launch_conv_p<3, 1>(p, in, out, wpk, bias, st);
+        else launch_conv_p<3, 0>(p, in, out, wpk, bias, st);
+    } else {
+        if (p.path == 2) launch_conv_p<1, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4) launch_conv_p<1, 4>(p, in, out, wpk, bias, st);
+        else if (p.path == 3) launch_conv_p<1, 3>(p, in, out, wpk, bias, st);
+        else if (p.path == 1) launch_conv_p<1, 1>(p, in, out, wpk, bias, st);
+        else launch_conv_p<1, 0>(p, in, out, wpk, bias, st);
+    }
+}
+
+// Resolve the per-layer Q values exactly like the layer loop does (yolo2_model.cpp:290-340, 379-399).
+static int resolve_q(yolo2_hip_ctx *c)
+{
+    std::vector<int> lists;   // concatenated block lists of split layers
+    const int na = (int)c->act_q.size();
+    int current_Qa = na ? c->act_q[0] : 0, route24_q = 0, pending = -1, ord = 0;
+    c->reorg_shift = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type == L_CONV) {
+            ConvPlan &p = c->plan[i];
+            p.C = l.c; p.N = l.n; p.K = l.size; p.H = l.h; p.W = l.w; p.leaky = l.leaky;
+            p.Qa_in = ord < na ? c->act_q[ord] : current_Qa;
+            p.Qa_out = ord + 1 < na ? c->act_q[ord + 1] : p.Qa_in;
+            p.Qw = ord < (int)c->weight_q.size() ? c->weight_q[ord] : 0;
+            p.Qb = ord < (int)c->bias_q.size() ? c->bias_q[ord] : 0;
+            if (pending >= 0) p.Qa_in = pending;
+            current_Qa = p.Qa_out;
+            if (i == 24) route24_q = current_Qa;
+            pending = -1;
+            // arithmetic form per block of 32 output channels; launches are grouped by form
+            const int MB = (l.n + 31) / 32, so = p.Qa_in + p.Qw - p.Qa_out, sb = p.Qb - p.Qa_out;
+            std::vector<int> groups[5];
+            std::vector<signed char> delta((size_t)MB, 0);
+            bool rescale = false;
+            if (c->wscale_mb[ord].size() != (size_t)MB) c->wscale_mb[ord].assign((size_t)MB, 0);
+            for (int mb = 0; mb < MB; ++mb) {
+                const int path = choose_path(so, sb, c->maxsum_mb[ord][mb], c->maxbias_mb[ord][mb],
+                                             c->maxabs_mb[ord].empty() ? -1 : c->maxabs_mb[ord][mb]);
+                groups[path].push_back(mb);
+                const int want = path == 4 ? 16 - so : 0;   // form D blocks keep w * 2^(16-s) in the packed buffer
+                delta[(size_t)mb] = (signed char)(want - c->wscale_mb[ord][(size_t)mb]);
+                rescale |= delta[(size_t)mb] != 0;
+                c->wscale_mb[ord][(size_t)mb] = (signed char)want;
+            }
+            if (rescale && !c->is_lane) {   // lanes share the parent's packed weights (and reach the same decisions)
+                signed char *dd = nullptr;
+                HIP_TRY(hipMalloc((void **)&dd, (size_t)MB), YOLO2_MMAP_ERROR);
+                HIP_TRY(hipMemcpy(dd, delta.data(), (size_t)MB, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+                const long per_mb = packed_weight_elems(l.c, l.n, l.size) / MB;
+                hipLaunchKernelGGL(k_scale_weight_blocks, dim3(std::min<unsigned>(blocks_for(per_mb, 256), 64), MB), dim3(256), 0,
+                                   nullptr, c->wpk + c->wpk_off[ord], per_mb, dd);
+                HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+                (void)hipFree(dd);
+            }
+            int dom = 0;
+            for (int k = 0; k < 5; ++k) {
+                c->path_counts[ord][k] = (int)groups[k].size();
+                if (groups[k].size() > groups[dom].size()) dom = k;
+            }
+            c->extra[i].clear();
+            p.args.mb_list = nullptr;
+            p.mb_count = 0;
+            p.path = dom;
+            {   // split-K bounds with the layer-wide maxima: form A arithmetic (no int32 overflow), every
+                // increment below 2^29 and the unclamped sum of one split below 2^30
+                const ShiftSpec o = make_shift(so);
+                const long long rnd = o.mag > 0 ? (1LL << (o.mag - 1)) : 0;
+                const long long tmax = so >= 0 ? (((long long)c->maxsum[ord] * 32768 + rnd) >> o.mag) : (1LL << 40);
+                const long long steps = (long long)((l.c + 3) / 4 / 4 + 1) * l.size * l.size;
+                const bool okA = choose_path(so, sb, c->maxsum[ord], c->maxbias[ord]) != 2;
+                p.splitk_ok = okA && tmax < (1LL << 29) && tmax * steps < (1LL << 30);
+            }
+            if ((int)groups[dom].size() != MB) {
+                p.mb_count = (int)groups[dom].size();
+                p.args.mb_list = (const int *)(uintptr_t)lists.size();   // offset for now, pointer once uploaded
+                lists.insert(lists.end(), groups[dom].begin(), groups[dom].end());
+                for (int k = 0; k < 5; ++k) {
+                    if (k == dom || groups[k].empty()) continue;
+                    ConvPlan e = p;
+                    e.path = k;
+                    e.mb_count = (int)groups[k].size();
+                    e.args.mb_list = (const int *)(uintptr_t)lists.size();
+                    lists.insert(lists.end(), groups[k].begin(), groups[k].end());
+                    c->extra[i].push_back(e);
+                }
+            }
+            ord++;
+        } else if (l.type == L_REORG) {
+            if (route24_q > 0) {
+                const int target = std::min(route24_q, current_Qa);
+                c->reorg_shift = current_Qa - target;
+                if (c->reorg_shift != 0) current_Qa = target;
+                pending = current_Qa;
+            }
+        }
+    }
+    c->final_q = current_Qa;
+    if (c->mb_lists) (void)hipFree(c->mb_lists);
+    c->mb_lists = nullptr;
+    if (!lists.empty()) {
+        HIP_TRY(hipMalloc((void **)&c->mb_lists, lists.size() * sizeof(int)), YOLO2_MMAP_ERROR);
+        HIP_TRY(hipMemcpy(c->mb_lists, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+        for (int i = 0; i < 32; ++i) {
+            if (kNet[i].type != L_CONV || !c->plan[i].mb_count) continue;
+            c->plan[i].args.mb_list = c->mb_lists + (uintptr_t)c->plan[i].args.mb_list;
+            for (auto &e : c->extra[i]) e.args.mb_list = c->mb_lists + (uintptr_t)e.args.mb_list;
+        }
+    }
+    return YOLO2_SUCCESS;
+}
+
+static int load_common(yolo2_hip_ctx *c, const short *w_dev, size_t n_weights, const short *b_dev, size_t n_bias,
+                       const int32_t *weight_q, int n_wq, const int32_t *bias_q, int n_bq, const int32_t *act_q, int n_aq)
+{
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights blob too small (%zu < %d)", n_weights, YOLO2_N_WEIGHTS);
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias blob too small (%zu < %d)", n_bias, YOLO2_N_BIAS);
+    if (n_wq < YOLO2_N_CONV || n_bq < YOLO2_N_CONV) return fail(YOLO2_ERROR, "Q tables too small for conv layers");
+    if (n_aq < 1) return fail(YOLO2_ERROR, "Activation Q table (iofm_Q.bin) is required for int16 inference.");
+    y2_destroy_lanes(c);   // they alias the weight buffers that are about to be replaced
+    c->weight_q.assign(weight_q, weight_q + n_wq);
+    c->bias_q.assign(bias_q, bias_q + n_bq);
+    c->act_q.assign(act_q, act_q + n_aq);
+
+    long wtot = 0, btot = 0;
+    int ord = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            c->wpk_off[ord] = wtot;
+            c->bias_off[ord] = btot;
+            wtot += packed_weight_elems(kNet[i].c, kNet[i].n, kNet[i].size);
+            btot += (long)((kNet[i].n + 31) / 32) * 32;
+            ord++;
+        }
+    if (c->wpk) (void)hipFree(c->wpk);
+    if (c->bias_pk) (void)hipFree(c->bias_pk);
+    c->wpk = c->bias_pk = nullptr;
+    HIP_TRY(hipMalloc((void **)&c->wpk, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&c->bias_pk, (size_t)btot * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(c->bias_pk, 0, (size_t)btot * 2), YOLO2_DMA_ERROR);
+    int *bound = nullptr, *bound_mb = nullptr, *bound_abs = nullptr;
+    int mb_total = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) mb_total += (kNet[i].n + 31) / 32;
+    HIP_TRY(hipMalloc((void **)&bound, sizeof(int) * YOLO2_N_CONV), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bound_mb, sizeof(int) * mb_total), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bound_abs, sizeof(int) * mb_total), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(bound, 0, sizeof(int) * YOLO2_N_CONV), YOLO2_DMA_ERROR);
+    int mb_off = 0;
+    std::vector<int> mb_offs;
+    std::vector<short> hb(YOLO2_N_BIAS);
+    HIP_TRY(hipMemcpy(hb.data(), b_dev, (size_t)YOLO2_N_BIAS * 2, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    long woff = 0, boff = 0;
+    ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        if (l.type != L_CONV) continue;
+        const long n = packed_weight_elems(l.c, l.n, l.size);
+        hipLaunchKernelGGL((k_repack_weights<short>), dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, w_dev + woff,
+                           c->wpk + c->wpk_off[ord], l.c, l.n, l.size * l.size);
+        hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(n / 4, 256), 1024)), dim3(256), 0, nullptr,
+                           (const short *)(c->wpk + c->wpk_off[ord]), n / 4, bound + ord);
+        const int MB = (l.n + 31) / 32;
+        hipLaunchKernelGGL(k_weight_bound_mb, dim3(MB), dim3(256), 0, nullptr, (const short *)(c->wpk + c->wpk_off[ord]),
+                           n / 4 / MB, bound_mb + mb_off, bound_abs + mb_off);
+        c->wscale_mb[ord].assign((size_t)MB, 0);   // freshly packed: unscaled
+        mb_offs.push_back(mb_off);
+        mb_off += MB;
+        HIP_TRY(hipMemcpyAsync(c->bias_pk + c->bias_off[ord], b_dev + boff, (size_t)l.n * 2, hipMemcpyDeviceToDevice, nullptr),
+                YOLO2_DMA_ERROR);
+        int mb = 0;
+        c->maxbias_mb[ord].assign(MB, 0);
+        for (int k = 0; k < l.n; ++k) {
+            const int v = std::abs((int)hb[boff + k]);
+            mb = std::max(mb, v);
+            c->maxbias_mb[ord][k / 32] = std::max(c->maxbias_mb[ord][k / 32], v);
+        }
+        c->maxbias[ord] = mb;
+        woff += yolo2_weight_len[ord];
+        boff += yolo2_bias_len[ord];
+        ord++;
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    HIP_TRY(hipMemcpy(c->maxsum, bound, sizeof(int) * YOLO2_N_CONV, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    {
+        std::vector<int> hm(mb_total), ha(mb_total);
+        HIP_TRY(hipMemcpy(hm.data(), bound_mb, sizeof(int) * mb_total, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+        HIP_TRY(hipMemcpy(ha.data(), bound_abs, sizeof(int) * mb_total, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+        int o = 0;
+        for (int i = 0; i < 32; ++i)
+            if (kNet[i].type == L_CONV) {
+                const int MB = (kNet[i].n + 31) / 32;
+                c->maxsum_mb[o].assign(hm.begin() + mb_offs[o], hm.begin() + mb_offs[o] + MB);
+                c->maxabs_mb[o].assign(ha.begin() + mb_offs[o], ha.begin() + mb_offs[o] + MB);
+                o++;
+            }
+    }
+    (void)hipFree(bound);
+    (void)hipFree(bound_mb);
+    (void)hipFree(bound_abs);
+    {
+        const int rq = resolve_q(c);
+        if (rq) return rq;
+    }
+    c->weights_loaded = true;
+    if (c->batch) {  // re-plan for the new Q values
+        const int b = c->batch;
+        c->batch = 0;
+        return yolo2_hip_set_batch(c, b);
+    }
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_load_weights_int16_dev(yolo2_hip_ctx *c, uint64_t weights_reorg_dev, size_t n_weights,
+                                                uint64_t bias_dev, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                                const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!weights_reorg_dev || !bias_dev || !weight_q || !bias_q || !act_q) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    return load_common(c, (const short *)(uintptr_t)weights_reorg_dev, n_weights, (const short *)(uintptr_t)bias_dev, n_bias,
+                       weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
+}
+
+extern "C" int yolo2_hip_load_weights_int16(yolo2_hip_ctx *c, const int16_t *weights_reorg, size_t n_weights,
+                                            const int16_t *bias, size_t n_bias, const int32_t *weight_q, int n_weight_q,
+                                            const int32_t *bias_q, int n_bias_q, const int32_t *act_q, int n_act_q)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!weights_reorg || !bias || !weight_q || !bias_q || !act_q) return fail(YOLO2_ERROR, "null argument");
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    short *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 2, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 2, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    const int rc = load_common(c, wd, YOLO2_N_WEIGHTS, bd, YOLO2_N_BIAS, weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
+    (void)hipDeviceSynchronize();
+    (void)hipFree(wd);
+    (void)hipFree(bd);
+    return rc;
+}
+
+extern "C" int yolo2_hip_layer_path(yolo2_hip_ctx *c, int ord)
+{
+    if (!c || !c->weights_loaded || ord < 0 || ord >= YOLO2_N_CONV) return -1;
+    int o = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            if (o == ord) return c->plan[i].path;
+            o++;
+        }
+    return -1;
+}
+
+extern "C" int yolo2_hip_layer_path_counts(yolo2_hip_ctx *c, int ord, int counts[5])
+{
+    if (!c || !c->weights_loaded || ord < 0 || ord >= YOLO2_N_CONV || !counts) return YOLO2_ERROR;
+    for (int k = 0; k < 5; ++k) counts[k] = c->path_counts[ord][k];
+    return YOLO2_SUCCESS;
+}
+
+static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
+{
+    t.g = make_geom(C, H, W, B);
+    HIP_TRY(hipMalloc((void **)&t.d, (size_t)t.g.items * 8), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(t.d, 0, (size_t)t.g.items * 8), YOLO2_DMA_ERROR);  // the zeros ARE the conv padding
+    return YOLO2_SUCCESS;
+}
+
+// Pixels-per-lane (P) decides tile count, occupancy and how evenly a layer's workgroups divide
+// over the 256 CUs; the best value depends on layer shape and batch.  Time each candidate once
+// per layer on the layer's own buffers (integer kernels: timing does not depend on the data) and
+// keep the fastest.  ~0.2 s at batch 64; disable with YOLO2_AUTOTUNE=0.
+static int autotune(yolo2_hip_ctx *c)
+{
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0), YOLO2_ERROR);
+    HIP_TRY(hipEventCreate(&e1), YOLO2_ERROR);
+    // In a real pass every layer meets its weights cold in L2 (the other layers' 100 MB went through
+    // since), so each timed launch is preceded by a 64 MB fill that evicts the L2s.  Without it a
+    // repeated launch finds its weights in L2 and, at small batch, the latency of the per-tap
+    // scalar weight loads - exactly what the split-K kernel avoids - is not seen.
+    const size_t flush_bytes = (size_t)64 << 20;
+    void *flush = nullptr;
+    HIP_TRY(hipMalloc(&flush, flush_bytes), YOLO2_MMAP_ERROR);
+    int ord = 0;
+    for (int i = 0; i < 32; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+        const Tensor &tout = c->t_out[i];
+        const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
+        const int CGout = (kNet[i].n + 3) / 4;
+        std::vector<ConvPlan *> subs{&c->plan[i]};
+        for (auto &e : c->extra[i]) subs.push_back(&e);
+        for (ConvPlan *sp : subs) {
+            float best = 1e30f;
+            int bestP = sp->P, bestPad = 0;
+            int bestSplit = 0, bestPP = 1;
+            const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
+            // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
+            for (int cfg = 0; cfg < 16; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14: 4 splits, 2 pixels per lane
+                const int P = cfg >= 12 ? 1 : 8 >> (cfg & 3);
+                const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
+                if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
+                ConvPlan cand = *sp;
+                cand.lds_pad = pad;
+                cand.splitk = 0;
+                cand.splitk_pp = 1;
+                if (cfg >= 12) {
+                    if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
+                    cand.splitk = cfg == 13 ? 8 : 4;
+                    cand.splitk_pp = cfg == 14 ? 2 : (cfg == 15 ? 4 : 1);
+                } else if (fs && atoi(fs) == 1 && sp->splitk_ok && c->extra[i].empty()) {
+                    ConvPlan probe = *sp;
+                    probe.splitk = 4;
+                    plan_conv(probe, tin.g, tout.g.cg_stride, out_base, CGout, 1);
+                    if (probe.splitk) continue;   // forced: skip the ordinary candidates where split-K is available
+                }
+                plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
+                if (cfg >= 12 && !cand.splitk) continue;
+                if (cfg == 14 && cand.splitk_pp != 2) continue;
+                if (cfg == 15 && cand.splitk_pp != 4) continue;
+                if (cand.P != P) continue;  // not available for this path / shape
+                float tmin = 1e30f;
+                for (int rep = 0; rep < 2; ++rep) {
+                    (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
+                    (void)hipEventRecord(e0, nullptr);
+                    launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr);
+                    (void)hipEventRecord(e1, nullptr);
+                    HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
+                    float t = 0;
+                    HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
+                    tmin = std::min(tmin, t);
+                }
+                if (getenv("YOLO2_VERBOSE"))
+                    fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
+                            cand.splitk, cand.grid.x, cand.grid.y, tmin * 1e3);
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; }
+            }
+            sp->lds_pad = bestPad;
+            sp->splitk = bestSplit;
+            sp->splitk_pp = bestPP;
+            plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
+        }
+        ord++;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(flush);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+static int set_batch_single(yolo2_hip_ctx *c, int batch);
+
+static void launch_maxpool(const Tensor &tin, const Tensor &tout, int B, hipStream_t st)
+{
+    const ActGeom &gi = tin.g, &go = tout.g;
+    const long n = (long)go.CG * B * go.H * go.W;
+    hipLaunchKernelGGL(k_maxpool2, dim3(blocks_for(n, 256)), dim3(256), 0, st, tin.d, tout.d, go.CG, B, go.H, go.W, gi.Wp, gi.PL,
+                       go.Wp, go.PL);
+}
+
+// Conv layers followed by a 2x2 pool (0, 2, 6, 10, 16) may run as ONE kernel that stores the pooled tensor
+// (k_conv_i16_pool); layer 16 also feeds the route to layer 26, so it stores the full-resolution tensor too.
+// Legal when every launch of the layer runs a packed-accumulator form (C / D).  timed: keep whichever of
+// {conv launches + k_maxpool2, fused launches} is faster on this batch (cold L2, like autotune); otherwise fuse
+// wherever legal.  YOLO2_NO_POOLFUSE=1 disables, YOLO2_POOLFUSE=1 forces it wherever legal.
+static int setup_pool_fusion(yolo2_hip_ctx *c, bool timed, bool default_on)
+{
+    for (bool &f : c->fuse_pool) f = false;
+    if (getenv("YOLO2_NO_POOLFUSE")) return YOLO2_SUCCESS;
+    const char *fe = getenv("YOLO2_POOLFUSE");
+    const bool force = fe && atoi(fe) == 1;
+    if (!default_on && !force) return YOLO2_SUCCESS;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    void *flush = nullptr;
+    const size_t flush_bytes = (size_t)64 << 20;
+    if (timed && !force) {
+        HIP_TRY(hipEventCreate(&e0), YOLO2_ERROR);
+        HIP_TRY(hipEventCreate(&e1), YOLO2_ERROR);
+        HIP_TRY(hipMalloc(&flush, flush_bytes), YOLO2_MMAP_ERROR);
+    }
+    int ord = 0;
+    for (int i = 0; i < 31; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const int o = ord++;
+        if (kNet[i + 1].type != L_MAX) continue;
+        const Tensor &tin = i == 0 ? c->t_in : c->t_out[i - 1];
+        const Tensor &tout = c->t_out[i], &tpool = c->t_out[i + 1];
+        const int full = i == 16 ? 1 : 0;
+        ConvPlan fp = c->plan[i];
+        bool ok = plan_conv_pool(fp, tin.g, tpool.g, full);
+        std::vector<ConvPlan> fx;
+        for (const auto &e : c->extra[i]) {
+            ConvPlan fe2 = e;
+            ok = ok && plan_conv_pool(fe2, tin.g, tpool.g, full);
+            fx.push_back(fe2);
+        }
+        if (!ok) continue;
+        c->fplan[i] = fp;
+        c->fextra[i] = fx;
+        if (!timed || force) { c->fuse_pool[i] = true; continue; }
+        const int2 *wp = (const int2 *)(c->wpk + c->wpk_off[o]);
+        const short *bp = c->bias_pk + c->bias_off[o];
+        float best[2] = {1e30f, 1e30f};
+        for (int variant = 0; variant < 2; ++variant)
+            for (int rep = 0; rep < 2; ++rep) {
+                (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
+                (void)hipEventRecord(e0, nullptr);
+                if (variant == 0) {
+                    launch_conv(c->plan[i], tin.d, tout.d, wp, bp, nullptr);
+                    for (const auto &e : c->extra[i]) launch_conv(e, tin.d, tout.d, wp, bp, nullptr);
+                    launch_maxpool(tout, tpool, c->batch, nullptr);
+                } else {
+                    launch_conv(fp, tin.d, tout.d, wp, bp, nullptr, tpool.d);
+                    for (const auto &e : fx) launch_conv(e, tin.d, tout.d, wp, bp, nullptr, tpool.d);
+                }
+                (void)hipEventRecord(e1, nullptr);
+                HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
+                float t = 0;
+                HIP_TRY(hipEventElapsedTime(&t, e0, e1), YOLO2_ERROR);
+                best[variant] = std::min(best[variant], t);
+            }
+        // Fused unless the separate kernels are clearly faster: within timing noise the fused form wins on traffic, and a choice that
+        // flips from run to run changes which layers the bench's per-kernel objects describe.
+        c->fuse_pool[i] = best[1] < best[0] * 1.05f;
+        if (getenv("YOLO2_VERBOSE"))
+            fprintf(stderr, "[yolo2_hip] L%d conv+pool: separate %.1f us, fused %.1f us -> %s\n", i, best[0] * 1e3, best[1] * 1e3,
+                    c->fuse_pool[i] ? "fused" : "separate");
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (flush) (void)hipFree(flush);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+static int make_lane(yolo2_hip_ctx *p, yolo2_hip_ctx **out)
+{
+    yolo2_hip_ctx *l = new (std::nothrow) yolo2_hip_ctx();
+    if (!l) return fail(YOLO2_ERROR, "out of host memory");
+    l->device = p->device;
+    l->is_lane = true;
+    l->wpk = p->wpk;
+    l->bias_pk = p->bias_pk;
+    memcpy(l->wpk_off, p->wpk_off, sizeof(p->wpk_off));
+    memcpy(l->bias_off, p->bias_off, sizeof(p->bias_off));
+    memcpy(l->maxsum, p->maxsum, sizeof(p->maxsum));
+    memcpy(l->maxbias, p->maxbias, sizeof(p->maxbias));
+    for (int o = 0; o < YOLO2_N_CONV; ++o) {
+        l->maxsum_mb[o] = p->maxsum_mb[o];
+        l->maxbias_mb[o] = p->maxbias_mb[o];
+        l->maxabs_mb[o] = p->maxabs_mb[o];
+    }
+    l->weight_q = p->weight_q;
+    l->bias_q = p->bias_q;
+    l->act_q = p->act_q;
+    int rc = resolve_q(l);
+    if (rc == YOLO2_SUCCESS && hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(YOLO2_ERROR, "hipStreamCreate failed");
+    if (rc == YOLO2_SUCCESS && hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess) rc = fail(YOLO2_ERROR, "hipEventCreate failed");
+    if (rc) { yolo2_hip_destroy(l); return rc; }
+    l->weights_loaded = true;
+    *out = l;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (batch <= 0 || batch > 4096) return fail(YOLO2_ERROR, "batch %d out of range", batch);
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "load weights before set_batch");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    // Lanes: three for batches 48..127 (measured +2 % over two at batch 64: one more launch to fill each tail; at
+    // batch 256 two are 1 % better), two otherwise from batch 16; YOLO2_LANES=n overrides.  Sizes differ by at
+    // most one frame (64 = 22 + 21 + 21).
+    int nl = (batch >= 48 && batch < 128) ? 3 : 2;
+    if (const char *e = getenv("YOLO2_LANES")) nl = std::max(1, atoi(e));
+    const bool want_lanes = !c->is_lane && nl > 1 && batch >= 8 * nl && !getenv("YOLO2_NO_LANES");
+    if (!want_lanes) {
+        if (c->laned) c->batch = 0;   // a laned parent owns no activation tensors: force set_batch_single to allocate
+        y2_destroy_lanes(c);
+        return set_batch_single(c, batch);
+    }
+    if (c->laned && c->batch == batch && (int)c->lanes.size() == nl) return YOLO2_SUCCESS;
+    y2_destroy_lanes(c);
+    y2_free_activations(c);
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming), YOLO2_ERROR);
+    c->lane_first.clear();
+    int first = 0;
+    for (int i = 0; i < nl; ++i) {
+        yolo2_hip_ctx *l = nullptr;
+        // The remainder goes to the LAST lanes: the first lane's launches are enqueued first in every step and it is the one that
+        // finishes last (kernel trace: by 0.6-3 ms of a 20 ms step at batch 64), so it gets the smaller share.
+        int frames = batch / nl + (i >= nl - batch % nl ? 1 : 0);
+        if (const char *sp = getenv("YOLO2_LANE_SPLIT")) {   // diagnostic: "20,22,22" (must sum to the batch)
+            std::vector<int> v;
+            for (const char *q = sp; *q;) { v.push_back(atoi(q)); while (*q && *q != ',') ++q; if (*q) ++q; }
+            int sum = 0;
+            for (int x : v) sum += x;
+            if ((int)v.size() == nl && sum == batch) frames = v[i];
+        }
+        int rc = make_lane(c, &l);
+        if (rc == YOLO2_SUCCESS) {
+            c->lanes.push_back(l);
+            c->lane_first.push_back(first);
+            rc = set_batch_single(l, frames);
+        }
+        if (rc) { y2_destroy_lanes(c); return rc; }
+        first += frames;
+    }
+    if (c->prof) (void)yolo2_hip_set_profiling(c->lanes[0], 1);
+    c->batch = batch;
+    c->laned = true;
+    return YOLO2_SUCCESS;
+}
+
+static int set_batch_single(yolo2_hip_ctx *c, int batch)
+{
+    if (c->batch != batch) {
+        y2_free_activations(c);
+        int rc;
+        if ((rc = alloc_tensor(c->t_in, 3, 416, 416, batch))) return rc;
+        if ((rc = alloc_tensor(c->t_cat, 1280, 13, 13, batch))) return rc;
+        for (int i = 0; i < 31; ++i) {
+            const LayerDesc &l = kNet[i];
+            if (l.type == L_CONV && i != 24) {
+                if ((rc = alloc_tensor(c->t_out[i], l.n, l.h, l.w, batch))) return rc;
+            } else if (l.type == L_MAX) {
+                if ((rc = alloc_tensor(c->t_out[i], l.c, l.h / 2, l.w / 2, batch))) return rc;
+            }
+        }
+        c->t_out[24] = c->t_cat;  // conv-24 output and the reorg output live in the concat tensor
+        c->t_out[27] = c->t_cat;  // (yolo2_model.cpp:97-104 does the same by arena placement)
+        c->batch = batch;
+    }
+    for (int i = 0; i < 32; ++i) {
+        if (kNet[i].type != L_CONV) continue;
+        const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+        const Tensor &tout = c->t_out[i];
+        const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
+        const int CGout = (kNet[i].n + 3) / 4;
+        plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
+        for (auto &e : c->extra[i]) plan_conv(e, tin.g, tout.g.cg_stride, out_base, CGout);
+    }
+    const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
+    if (fp && atoi(fp) > 0) {
+        for (int i = 0; i < 32; ++i) {
+            if (kNet[i].type != L_CONV) continue;
+            const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
+            const Tensor &tout = c->t_out[i];
+            plan_conv(c->plan[i], tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0),
+                      (kNet[i].n + 3) / 4, atoi(fp));
+            for (auto &e : c->extra[i])
+                plan_conv(e, tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0), (kNet[i].n + 3) / 4, atoi(fp));
+        }
+        HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);   // (the tensors' zero fills ran on the null stream)
+        return setup_pool_fusion(c, false, false);      // fixed tile shapes: fusion only on request (YOLO2_POOLFUSE=1)
+    }
+    const char *at = getenv("YOLO2_AUTOTUNE");
+    if (!(at && at[0] == '0')) {
+        const int rc = autotune(c);
+        return rc ? rc : setup_pool_fusion(c, true, true);
+    }
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+    return setup_pool_fusion(c, false, true);
+}
+
+extern "C" int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *c, int layer_idx)
+{
+    if (!c || layer_idx < 0 || layer_idx > 31 || !c->batch) return 0;
+    if (c->laned) return yolo2_hip_layer_pool_fused(c->lanes[0], layer_idx);
+    return c->fuse_pool[layer_idx] ? 1 : 0;
+}
+
+extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x, int *grid_y, int *block, int *lds_bytes,
+                                          int *ppl)
+{
+    if (!c || !c->batch) return fail(YOLO2_ERROR, "set_batch first");
+    if (c->laned) return yolo2_hip_conv_launch_info(c->lanes[0], ord, grid_x, grid_y, block, lds_bytes, ppl);
+    int o = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            if (o == ord) {
+                const ConvPlan &pl = c->fuse_pool[i] ? c->fplan[i] : c->plan[i];
+                if (grid_x) *grid_x = pl.grid.x;
+                if (grid_y) *grid_y = pl.grid.y;
+                if (block) *block = 256;
+                if (lds_bytes) *lds_bytes = pl.lds_bytes;
+                if (ppl) *ppl = pl.splitk ? 0 : pl.P;
+                return YOLO2_SUCCESS;
+            }
+            o++;
+        }
+    return fail(YOLO2_ERROR, "bad conv ordinal %d", ord);
+}
+
+extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, int batch, uint64_t region_dev,
+                                         int *final_q, void *stream)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "weights not loaded");
+    if (!frames_dev || !region_dev) return fail(YOLO2_ERROR, "null buffer address");
+    if (batch != c->batch) {
+        const int rc = yolo2_hip_set_batch(c, batch);
+        if (rc) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (c->laned) {   // fork the two half-batches onto the lane streams, join back into the caller's stream
+        const int nl = (int)c->lanes.size();
+        HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
+        for (int i = 0; i < nl; ++i) {
+            yolo2_hip_ctx *l = c->lanes[i];
+            const uint64_t first = (uint64_t)c->lane_first[i];
+            HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
+            const int rc = yolo2_hip_run_batch_int16(l, frames_dev + first * YOLO2_FRAME_ELEMS * sizeof(float), l->batch,
+                                                     region_dev + first * YOLO2_REGION_ELEMS * sizeof(int16_t), final_q,
+                                                     l->lane_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
+            HIP_TRY(hipStreamWaitEvent(st, l->ev_join, 0), YOLO2_ERROR);
+        }
+        c->final_q = c->lanes[0]->final_q;
+        return YOLO2_SUCCESS;
+    }
+    const float *frames = (const float *)(uintptr_t)frames_dev;
+    short *region = (short *)(uintptr_t)region_dev;
+    const int B = batch;
+    const float scale = ldexpf(1.0f, c->act_q[0]);
+
+    if (c->prof) {
+        const int rc = y2_ensure_prof_events(c);
+        if (rc) return rc;
+    }
+    hipEvent_t *ev = c->prof ? c->ev[c->prof_runs % yolo2_hip_ctx::kProfSlots] : nullptr;
+    if (ev) HIP_TRY(hipEventRecord(ev[0], st), YOLO2_ERROR);
+    {  // input quantise + pack (yolo2_model.cpp:257-278); its time is booked to layer 0
+        const ActGeom &g = c->t_in.g;
+        hipLaunchKernelGGL(k_pack_input, dim3(blocks_for((long)B * g.H * g.W, 256)), dim3(256), 0, st, frames, c->t_in.d, B,
+                           g.H, g.W, g.Wp, g.PL, scale);
+    }
+    int ord = 0;
+    const Tensor *cur = &c->t_in;
+    for (int i = 0; i < 32; ++i) {
+        const LayerDesc &l = kNet[i];
+        switch (l.type) {
+        case L_CONV: {
+            const Tensor *tin = i == 26 ? &c->t_out[16] : (i == 29 ? &c->t_cat : cur);
+            const int2 *wp = (const int2 *)(c->wpk + c->wpk_off[ord]);
+            const short *bp = c->bias_pk + c->bias_off[ord];
+            if (c->fuse_pool[i]) {   // conv + leaky + pool in one kernel: stores layer i+1's tensor (and layer 16's own)
+                launch_conv(c->fplan[i], tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
+                for (const auto &e : c->fextra[i]) launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
+            } else {
+                launch_conv(c->plan[i], tin->d, c->t_out[i].d, wp, bp, st);
+                for (const auto &e : c->extra[i])   // blocks of this layer that need another arithmetic form
+                    launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st);
+            }
+            cur = &c->t_out[i];
+            ord++;
+            break;
+        }
+        case L_MAX: {
+            if (!c->fuse_pool[i - 1]) launch_maxpool(*cur, c->t_out[i], B, st);
+            cur = &c->t_out[i];
+            break;
+        }
+        case L_REORG: {
+            const ActGeom &gi = cur->g, &go = c->t_cat.g;
+            hipLaunchKernelGGL(k_reorg, dim3(blocks_for((long)B * 256 * 169, 256)), dim3(256), 0, st, (const short *)cur->d,
+                               (short *)c->t_cat.d, B, gi.Wp, gi.PL, gi.cg_stride, go.Wp, go.PL, go.cg_stride, c->reorg_shift);
+            cur = &c->t_cat;
+            break;
+        }
+        case L_ROUTE:
+            break;  // concat by placement (yolo2_model.cpp:404-405)
+        case L_REGION: {
+            const ActGeom &g = cur->g;
+            hipLaunchKernelGGL(k_unpack_dense, dim3(blocks_for((long)B * 425 * 169, 256)), dim3(256), 0, st,
+                               (const short *)cur->d, region, B, 425, 13, 13, g.Wp, g.PL, g.cg_stride);
+            break;
+        }
+        }
+        if (ev) (void)hipEventRecord(ev[i + 1], st);
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    if (ev) c->prof_runs++;
+    if (final_q) *final_q = c->final_q;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_batch_int16_host(yolo2_hip_ctx *c, const float *frames, int batch, int16_t *region,
+                                              int *final_q)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    float *fd = nullptr;
+    short *rd = nullptr;
+    HIP_TRY(hipMalloc((void **)&fd, (size_t)batch * YOLO2_FRAME_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&rd, (size_t)batch * YOLO2_REGION_ELEMS * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(fd, frames, (size_t)batch * YOLO2_FRAME_ELEMS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    int rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)fd, batch, (uint64_t)(uintptr_t)rd, final_q, nullptr);
+    if (rc == YOLO2_SUCCESS) {
+        hipError_t e = hipMemcpy(region, rd, (size_t)batch * YOLO2_REGION_ELEMS * 2, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(YOLO2_DMA_ERROR, "D2H of region tensor failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(fd);
+    (void)hipFree(rd);
+    return rc;
+}
+
+extern "C" int yolo2_hip_debug_layer_output(yolo2_hip_ctx *c, int layer_idx, int frame, int16_t *out, size_t cap,
+                                            size_t *out_elems)
+{
+    if (!c || !out) return fail(YOLO2_ERROR, "null argument");
+    if (layer_idx < -1 || layer_idx > 30 || !c->batch || frame < 0 || frame >= c->batch) return fail(YOLO2_ERROR, "bad layer/frame");
+    if (c->laned) {
+        int li = (int)c->lanes.size() - 1;
+        while (li > 0 && frame < c->lane_first[li]) --li;
+        return yolo2_hip_debug_layer_output(c->lanes[li], layer_idx, frame - c->lane_first[li], out, cap, out_elems);
+    }
+    if (layer_idx >= 0 && c->fuse_pool[layer_idx] && layer_idx != 16)
+        return fail(YOLO2_ERROR, "layer %d's tensor is not materialised: conv + pool run fused (YOLO2_NO_POOLFUSE=1 keeps it)", layer_idx);
+    // layer -1 = the quantised network input (yolo2_model.cpp:257-273), 3 x 416 x 416
+    const LayerDesc &l = kNet[layer_idx < 0 ? 0 : layer_idx];
+    if (layer_idx >= 0 && l.type == L_ROUTE) return fail(YOLO2_ERROR, "route layers have no tensor of their own");
+    const Tensor &t = layer_idx < 0 ? c->t_in : c->t_out[layer_idx];
+    int C = layer_idx < 0 ? 3 : (l.type == L_MAX ? l.c : l.n), H = t.g.H, W = t.g.W;
+    const short *base = (const short *)t.d;
+    if (layer_idx == 24) base += (long)64 * t.g.cg_stride * 4;  // channels 256.. of the concat tensor
+    const int W8 = (W + 7) & ~7;
+    const size_t n = (size_t)C * H * W8;
+    if (out_elems) *out_elems = n;
+    if (cap < n) return fail(YOLO2_ERROR, "output buffer too small (%zu < %zu)", cap, n);
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    short *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&tmp, n * 2), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemset(tmp, 0, n * 2), YOLO2_DMA_ERROR);
+    hipLaunchKernelGGL(k_items_to_ref, dim3(blocks_for((long)C * H * W, 256)), dim3(256), 0, nullptr, base, tmp, C, H, W, W8,
+                       t.g.Wp, t.g.PL, t.g.cg_stride, frame);
+    hipError_t e = hipMemcpy(out, tmp, n * 2, hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    if (e != hipSuccess) return fail(YOLO2_DMA_ERROR, "D2H failed: %s", hipGetErrorString(e));
+    return YOLO2_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------- device work of the driver tier's per-layer calls
+// (yolo2_driver.hip holds the lock, has bound the device and synchronises afterwards; everything here goes to the null stream)
+
+namespace {
+struct DrvScratch {   // grow-only
+    void *in_items = nullptr, *out_items = nullptr, *wpk = nullptr, *bias_pk = nullptr;
+    size_t in_cap = 0, out_cap = 0, wpk_cap = 0, bias_cap = 0;
+    int *bound = nullptr;   // [max sum, max sum (1 block), max |w|, scale byte]
+} g_scr;
+}  // namespace
+
+void y2_drv_release_i16(void)
+{
+    for (void *p : {g_scr.in_items, g_scr.out_items, g_scr.wpk, g_scr.bias_pk, (void *)g_scr.bound})
+        if (p) (void)hipFree(p);
+    g_scr = DrvScratch();
+}
+
+static int max_abs_i16_dev(const short *dev, int n, int *out)
+{
+    std::vector<short> h(n);
+    HIP_TRY(hipMemcpy(h.data(), dev, (size_t)n * 2, hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    int m = 0;
+    for (short v : h) m = std::max(m, std::abs((int)v));
+    *out = m;
+    return YOLO2_SUCCESS;
+}
+
+int y2_drv_conv_i16(const short *in, short *out, const short *w, const short *beta, int ifm_num, int ofm_num, int ksize, int kstride,
+                    int input_w, int input_h, int output_w, int output_h, int padding, int is_nl, int qw, int qa_in, int qa_out, int qb,
+                    int *path_out)
+{
+    hipStream_t st = nullptr;
+    const int so = qa_in + qw - qa_out, sb = qb - qa_out;
+    if (!g_scr.bound) HIP_TRY(hipMalloc((void **)&g_scr.bound, 4 * sizeof(int)), YOLO2_MMAP_ERROR);
+    bool tiled = kstride == 1 && ((ksize == 3 && padding == 1) || (ksize == 1 && padding == 0));
+    if (tiled) {  // very wide images: the halo of a 64-pixel tile must fit the LDS staging scheme
+        const ActGeom g = make_geom(ifm_num, input_h, input_w, 1);
+        if (tile_items_bound(g, 64, ksize == 3 ? g.Wp + 1 : 0) > kMaxTileItems) tiled = false;
+    }
+    if (!tiled) {
+        *path_out = -1;
+        const int n = ofm_num * output_h * output_w;
+        hipLaunchKernelGGL(k_conv_ref_i16, dim3(blocks_for(n, 256)), dim3(256), 0, st, in, out, w, beta, ifm_num, ofm_num,
+                           ksize, kstride, input_w, input_h, output_w, output_h, padding, is_nl ? 1 : 0, so, sb);
+        HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+        return YOLO2_SUCCESS;
+    }
+
+    const ActGeom gi = make_geom(ifm_num, input_h, input_w, 1), go = make_geom(ofm_num, output_h, output_w, 1);
+    const long wpk_elems = packed_weight_elems(ifm_num, ofm_num, ksize);
+    const int MB = (ofm_num + 31) / 32;
+    int rc;
+    if ((rc = y2_ensure(&g_scr.in_items, &g_scr.in_cap, (size_t)gi.items * 8))) return rc;
+    if ((rc = y2_ensure(&g_scr.out_items, &g_scr.out_cap, (size_t)go.items * 8))) return rc;
+    if ((rc = y2_ensure(&g_scr.wpk, &g_scr.wpk_cap, (size_t)wpk_elems * 2))) return rc;
+    if ((rc = y2_ensure(&g_scr.bias_pk, &g_scr.bias_cap, (size_t)MB * 32 * 2))) return rc;
+    HIP_TRY(hipMemsetAsync(g_scr.in_items, 0, (size_t)gi.items * 8, st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemsetAsync(g_scr.bias_pk, 0, (size_t)MB * 32 * 2, st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemsetAsync(g_scr.bound, 0, sizeof(int), st), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpyAsync(g_scr.bias_pk, beta, (size_t)ofm_num * 2, hipMemcpyDeviceToDevice, st), YOLO2_DMA_ERROR);
+    hipLaunchKernelGGL(k_ref_to_items, dim3(blocks_for((long)ifm_num * input_h * input_w, 256)), dim3(256), 0, st, in,
+                       (short *)g_scr.in_items, ifm_num, input_h, input_w, (input_w + 7) & ~7, gi.Wp, gi.cg_stride);
+    hipLaunchKernelGGL((k_repack_weights<short>), dim3(blocks_for(wpk_elems, 256)), dim3(256), 0, st, w, (short *)g_scr.wpk,
+                       ifm_num, ofm_num, ksize * ksize);
+    hipLaunchKernelGGL(k_weight_bound, dim3(std::min<unsigned>(blocks_for(wpk_elems / 4, 256), 1024)), dim3(256), 0, st,
+                       (const short *)g_scr.wpk, wpk_elems / 4, g_scr.bound);
+    // whole layer as one "block": its largest |w| decides whether the shift can be folded into the weights (form D)
+    hipLaunchKernelGGL(k_weight_bound_mb, dim3(1), dim3(256), 0, st, (const short *)g_scr.wpk, wpk_elems / 4, g_scr.bound + 1,
+                       g_scr.bound + 2);
+    int hbound[3] = {0, 0, 0}, maxb = 0;
+    HIP_TRY(hipMemcpy(hbound, g_scr.bound, sizeof(hbound), hipMemcpyDeviceToHost), YOLO2_DMA_ERROR);
+    const int maxsum = hbound[0], maxabs = hbound[2];
+    if ((rc = max_abs_i16_dev(beta, ofm_num, &maxb))) return rc;
+
+    ConvPlan p;
+    p.args.mb_list = nullptr;
+    p.C = ifm_num; p.N = ofm_num; p.K = ksize; p.H = input_h; p.W = input_w; p.leaky = is_nl ? 1 : 0;
+    p.Qw = qw; p.Qa_in = qa_in; p.Qa_out = qa_out; p.Qb = qb;
+    p.path = choose_path(so, sb, maxsum, maxb, maxabs);
+    if (p.path == 4) {   // this call's packed copy carries w * 2^(16-s)
+        HIP_TRY(hipMemsetAsync(g_scr.bound + 3, 16 - so, 1, st), YOLO2_DMA_ERROR);
+        hipLaunchKernelGGL(k_scale_weight_blocks, dim3(std::min<unsigned>(blocks_for(wpk_elems, 256), 256), 1), dim3(256), 0, st,
+                           (short *)g_scr.wpk, wpk_elems, (const signed char *)(g_scr.bound + 3));
+    }
+    plan_conv(p, gi, go.cg_stride, kLead, go.CG);
+    *path_out = p.path;
+    launch_conv(p, (const int2 *)g_scr.in_items, (int2 *)g_scr.out_items, (const int2 *)g_scr.wpk, (const short *)g_scr.bias_pk, st);
+    hipLaunchKernelGGL(k_items_to_ref, dim3(blocks_for((long)ofm_num * output_h * output_w, 256)), dim3(256), 0, st,
+                       (const short *)g_scr.out_items, out, ofm_num, output_h, output_w, (output_w + 7) & ~7, go.Wp, go.PL,
+                       go.cg_stride, 0);
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+void y2_drv_pool_i16(const short *in, short *out, int channels, int ksize, int kstride, int input_w, int input_h, int output_w, int output_h)
+{
+    // padding is forced to 0 by the scheduler (core_scheduler.cpp:72-73); pad VALUE -32768 (core_io.cpp:96-103)
+    const int n = channels * output_h * output_w;
+    hipLaunchKernelGGL((k_pool_ref<short>), dim3(blocks_for(n, 256)), dim3(256), 0, nullptr, in, out, channels, ksize, kstride, input_w,
+                       input_h, output_w, output_h, (short)-32768);
+}

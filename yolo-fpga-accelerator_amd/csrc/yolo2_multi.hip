@@ -16,10 +16,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -49,9 +51,16 @@ struct Rccl {
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;   // the file ncclBroadcast was resolved from (dladdr): a process that has already mapped a librccl
+                        // with the same soname (torch ships its own) gets THAT copy from dlopen, and the record says so
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -72,10 +81,17 @@ const Rccl *rccl()
         Y2_SYM(CommInitAll, "ncclCommInitAll")
         Y2_SYM(CommDestroy, "ncclCommDestroy")
         Y2_SYM(Broadcast, "ncclBroadcast")
+        Y2_SYM(AllReduce, "ncclAllReduce")
         Y2_SYM(GroupStart, "ncclGroupStart")
         Y2_SYM(GroupEnd, "ncclGroupEnd")
+        Y2_SYM(CommCount, "ncclCommCount")
+        Y2_SYM(CommUserRank, "ncclCommUserRank")
+        Y2_SYM(CommCuDevice, "ncclCommCuDevice")
+        Y2_SYM(GetVersion, "ncclGetVersion")
         Y2_SYM(GetErrorString, "ncclGetErrorString")
 #undef Y2_SYM
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void *>(g_rccl.Broadcast), &info) && info.dli_fname) g_rccl.path = info.dli_fname;
     });
     return g_rccl.h ? &g_rccl : nullptr;
 }
@@ -101,23 +117,42 @@ struct Member {
 
 // THE broadcast (both launch models): every blob travels as bytes from `root`'s buffer to every other member's.
 // `members` are this PROCESS's members (all of them with ncclCommInitAll, exactly one with ncclCommInitRank);
-// the calls of one process are grouped, as RCCL requires when one thread drives several devices.
-int bcast_blobs(std::vector<Member> &members, const std::vector<size_t> &bytes, int root)
+// the calls of one process are grouped, as RCCL requires when one thread drives several devices.  A failed call inside
+// a group does not skip ncclGroupEnd (an open group would swallow every later RCCL call of this thread).
+int bcast_blobs(std::vector<Member> &members, const std::vector<size_t> &bytes, int root, double *ms_out = nullptr)
 {
     const Rccl *R = rccl();
     if (!R) return mfail(YOLO2_INIT_ERROR, "%s", g_rccl_err.c_str());
-    for (size_t k = 0; k < bytes.size(); ++k) {
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = YOLO2_SUCCESS;
+    for (size_t k = 0; k < bytes.size() && rc == YOLO2_SUCCESS; ++k) {
         RCCL_TRY(R->GroupStart());
         for (Member &m : members) {
-            HIPM_TRY(hipSetDevice(m.device), YOLO2_INIT_ERROR);
-            RCCL_TRY(R->Broadcast(m.bufs[k], m.bufs[k], bytes[k], ncclInt8, root, m.comm, m.stream));
+            if (hipSetDevice(m.device) != hipSuccess) { rc = mfail(YOLO2_INIT_ERROR, "hipSetDevice(%d) failed", m.device); break; }
+            const ncclResult_t r = R->Broadcast(m.bufs[k], m.bufs[k], bytes[k], ncclInt8, root, m.comm, m.stream);
+            if (r != ncclSuccess) { rc = mfail(YOLO2_DMA_ERROR, "ncclBroadcast failed: %s", R->GetErrorString(r)); break; }
         }
-        RCCL_TRY(R->GroupEnd());
+        const ncclResult_t ge = R->GroupEnd();
+        if (ge != ncclSuccess && rc == YOLO2_SUCCESS) rc = mfail(YOLO2_DMA_ERROR, "ncclGroupEnd failed: %s", R->GetErrorString(ge));
     }
-    for (Member &m : members) {
-        HIPM_TRY(hipSetDevice(m.device), YOLO2_INIT_ERROR);
-        HIPM_TRY(hipStreamSynchronize(m.stream), YOLO2_DMA_ERROR);
+    for (Member &m : members) {   // drain what was enqueued, also on failure
+        if ((hipSetDevice(m.device) != hipSuccess || hipStreamSynchronize(m.stream) != hipSuccess) && rc == YOLO2_SUCCESS)
+            rc = mfail(YOLO2_DMA_ERROR, "synchronising the broadcast stream of device %d failed", m.device);
     }
+    if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+// Agreement on a status word across the communicator (one-process-per-device model): every rank contributes its local
+// status (0 or a negative YOLO2_* code), every rank receives the minimum.  This is what makes a failure COLLECTIVE: a root
+// that cannot read its blobs, or a rank that cannot allocate, does not leave the others blocked inside the broadcast.
+int agree_status(const Rccl *R, int device, ncclComm_t comm, hipStream_t stream, int *dev_word, int local, int *agreed)
+{
+    HIPM_TRY(hipSetDevice(device), YOLO2_INIT_ERROR);
+    HIPM_TRY(hipMemcpyAsync(dev_word, &local, sizeof(int), hipMemcpyHostToDevice, stream), YOLO2_DMA_ERROR);
+    RCCL_TRY(R->AllReduce(dev_word, dev_word, 1, ncclInt32, ncclMin, comm, stream));
+    HIPM_TRY(hipMemcpyAsync(agreed, dev_word, sizeof(int), hipMemcpyDeviceToHost, stream), YOLO2_DMA_ERROR);
+    HIPM_TRY(hipStreamSynchronize(stream), YOLO2_DMA_ERROR);
     return YOLO2_SUCCESS;
 }
 
@@ -153,15 +188,26 @@ struct RankState {
     ncclComm_t comm = nullptr;
     int nranks = 1, rank = 0, device = 0;
     hipStream_t stream = nullptr;
+    std::mutex use;              // held while a collective of this rank is in flight (finalize waits for it)
+    double last_bcast_ms = 0;    // the most recent weight broadcast through this communicator
+    size_t last_bcast_bytes = 0;
+    int bcasts = 0;
 };
+// Contexts that joined a communicator.  The states are shared_ptr: a caller takes its own reference under g_rank_mu and keeps
+// the state alive while it uses it, whatever a concurrent init_rank / finalize of ANOTHER context does to the vector.
 static std::mutex g_rank_mu;
-static std::vector<std::pair<yolo2_hip_ctx *, RankState>> g_ranks;   // contexts that joined a communicator
+static std::vector<std::pair<yolo2_hip_ctx *, std::shared_ptr<RankState>>> g_ranks;
 
-static RankState *rank_state(yolo2_hip_ctx *c)
+static std::shared_ptr<RankState> rank_state(yolo2_hip_ctx *c)   // g_rank_mu must be held
 {
     for (auto &p : g_ranks)
-        if (p.first == c) return &p.second;
+        if (p.first == c) return p.second;
     return nullptr;
+}
+static std::shared_ptr<RankState> rank_state_locked(yolo2_hip_ctx *c)
+{
+    std::lock_guard<std::mutex> lk(g_rank_mu);
+    return rank_state(c);
 }
 
 extern "C" int yolo2_hip_rccl_unique_id(void *id128)
@@ -184,67 +230,124 @@ extern "C" int yolo2_hip_rccl_init_rank(yolo2_hip_ctx *ctx, int device, const vo
     std::lock_guard<std::mutex> lk(g_rank_mu);
     if (rank_state(ctx)) return mfail(YOLO2_ERROR, "this context already belongs to a communicator");
     HIPM_TRY(hipSetDevice(device), YOLO2_INIT_ERROR);
-    RankState st;
-    st.nranks = nranks; st.rank = rank; st.device = device;
+    auto st = std::make_shared<RankState>();
+    st->nranks = nranks; st->rank = rank; st->device = device;
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    RCCL_TRY(R->CommInitRank(&st.comm, nranks, id, rank));
-    HIPM_TRY(hipStreamCreateWithFlags(&st.stream, hipStreamNonBlocking), YOLO2_ERROR);
+    RCCL_TRY(R->CommInitRank(&st->comm, nranks, id, rank));
+    if (hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)R->CommDestroy(st->comm);
+        return mfail(YOLO2_ERROR, "stream creation for the communicator failed");
+    }
     g_ranks.emplace_back(ctx, st);
     return YOLO2_SUCCESS;
 }
 
 extern "C" void yolo2_hip_rccl_finalize(yolo2_hip_ctx *ctx)
 {
-    std::lock_guard<std::mutex> lk(g_rank_mu);
-    for (size_t i = 0; i < g_ranks.size(); ++i)
-        if (g_ranks[i].first == ctx) {
-            RankState &st = g_ranks[i].second;
-            (void)hipSetDevice(st.device);
-            if (st.comm && rccl()) (void)rccl()->CommDestroy(st.comm);
-            if (st.stream) (void)hipStreamDestroy(st.stream);
-            g_ranks.erase(g_ranks.begin() + (long)i);
-            return;
-        }
+    std::shared_ptr<RankState> st;
+    {
+        std::lock_guard<std::mutex> lk(g_rank_mu);
+        for (size_t i = 0; i < g_ranks.size(); ++i)
+            if (g_ranks[i].first == ctx) {
+                st = g_ranks[i].second;
+                g_ranks.erase(g_ranks.begin() + (long)i);
+                break;
+            }
+    }
+    if (!st) return;
+    std::lock_guard<std::mutex> use(st->use);   // a collective still in flight on this rank finishes first
+    (void)hipSetDevice(st->device);
+    if (st->comm && rccl()) (void)rccl()->CommDestroy(st->comm);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    st->comm = nullptr;
+    st->stream = nullptr;
+}
+
+// What the communicator itself says (ncclCommCount / ncclCommUserRank / ncclCommCuDevice), the library it was resolved from
+// and the last weight broadcast through it: lets a launcher prove that RCCL saw N ranks (bench.py's "rccl" object).
+extern "C" int yolo2_hip_rccl_info(yolo2_hip_ctx *ctx, yolo2_hip_rccl_info_t *out)
+{
+    if (!ctx || !out) return mfail(YOLO2_ERROR, "null argument");
+    const std::shared_ptr<RankState> st = rank_state_locked(ctx);
+    if (!st) return mfail(YOLO2_ERROR, "yolo2_hip_rccl_init_rank() has not been called for this context");
+    const Rccl *R = rccl();
+    if (!R) return mfail(YOLO2_INIT_ERROR, "%s", g_rccl_err.c_str());
+    std::lock_guard<std::mutex> use(st->use);
+    if (!st->comm) return mfail(YOLO2_ERROR, "the communicator has been finalized");
+    memset(out, 0, sizeof(*out));
+    RCCL_TRY(R->CommCount(st->comm, &out->nranks));
+    RCCL_TRY(R->CommUserRank(st->comm, &out->rank));
+    RCCL_TRY(R->CommCuDevice(st->comm, &out->device));
+    RCCL_TRY(R->GetVersion(&out->version));
+    out->bcasts = st->bcasts;
+    out->last_bcast_ms = st->last_bcast_ms;
+    out->last_bcast_bytes = (uint64_t)st->last_bcast_bytes;
+    snprintf(out->lib_path, sizeof(out->lib_path), "%s", R->path.c_str());
+    return YOLO2_SUCCESS;
 }
 
 // Root passes the host blobs, every other rank nullptr; all ranks receive identical device copies and load them.
+// Failure is collective: every rank does its local part first (root: argument checks, allocation, H2D; others: allocation),
+// the ranks then AGREE on a status word, and either all of them run the broadcast or all of them return an error - no rank is
+// left waiting inside ncclBroadcast for a root that has already given up.  The same agreement follows the per-rank load.
+// (A rank that cannot even reach the agreement - its process died - is the launcher's business: torchrun / mpirun end the job.)
 template <typename T, typename LoadFn>
-static int load_bcast(yolo2_hip_ctx *ctx, const T *weights, size_t n_weights, const T *bias, size_t n_bias, int32_t *qrec, int root,
-                      LoadFn load)
+static int load_bcast(yolo2_hip_ctx *ctx, const T *weights, size_t n_weights, const T *bias, size_t n_bias, int32_t *qrec, int local_rc,
+                      int root, LoadFn load)
 {
-    RankState *st;
-    {
-        std::lock_guard<std::mutex> lk(g_rank_mu);
-        st = rank_state(ctx);
-    }
+    const std::shared_ptr<RankState> st = rank_state_locked(ctx);
     if (!st) return mfail(YOLO2_ERROR, "yolo2_hip_rccl_init_rank() has not been called for this context");
+    const Rccl *R = rccl();
+    if (!R) return mfail(YOLO2_INIT_ERROR, "%s", g_rccl_err.c_str());
+    std::lock_guard<std::mutex> use(st->use);
+    if (!st->comm) return mfail(YOLO2_ERROR, "the communicator has been finalized");
+    // `root` must be the same number on every rank (it is an argument of the collective); a bad value is bad everywhere
     if (root < 0 || root >= st->nranks) return mfail(YOLO2_ERROR, "bad root rank %d", root);
     const bool is_root = st->rank == root;
-    if (is_root && (!weights || !bias)) return mfail(YOLO2_ERROR, "the root rank must pass the weight blobs");
-    if (is_root && (n_weights < YOLO2_N_WEIGHTS || n_bias < YOLO2_N_BIAS)) return mfail(YOLO2_ERROR, "weight blobs too small");
     HIPM_TRY(hipSetDevice(st->device), YOLO2_INIT_ERROR);
     void *wd = nullptr, *bd = nullptr, *qd = nullptr;
+    int *word = nullptr;
     const size_t wbytes = (size_t)YOLO2_N_WEIGHTS * sizeof(T), bbytes = (size_t)YOLO2_N_BIAS * sizeof(T), qbytes = kQRec * sizeof(int32_t);
-    auto release = [&]() { (void)hipFree(wd); (void)hipFree(bd); (void)hipFree(qd); };
-    if (hipMalloc(&wd, wbytes) != hipSuccess || hipMalloc(&bd, bbytes) != hipSuccess || hipMalloc(&qd, qbytes) != hipSuccess) {
-        release();
-        return mfail(YOLO2_MMAP_ERROR, "device buffers for the weight broadcast could not be allocated");
-    }
-    if (is_root) {
-        if (hipMemcpy(wd, weights, wbytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(bd, bias, bbytes, hipMemcpyHostToDevice) != hipSuccess ||
-            hipMemcpy(qd, qrec, qbytes, hipMemcpyHostToDevice) != hipSuccess) {
-            release();
-            return mfail(YOLO2_DMA_ERROR, "H2D of the weight blobs failed");
-        }
-    }
+    auto release = [&]() { (void)hipFree(wd); (void)hipFree(bd); (void)hipFree(qd); (void)hipFree(word); };
+    // the status word first: without it this rank cannot take part in the agreement at all
+    if (hipMalloc((void **)&word, sizeof(int)) != hipSuccess) return mfail(YOLO2_MMAP_ERROR, "device word for the status agreement could not be allocated");
+    // ---- local part; errors are recorded, not returned
+    int local = local_rc;
+    std::string local_msg = local ? yolo2_hip_last_error() : "";
+    auto note = [&](int code, const char *msg) { if (local == YOLO2_SUCCESS) { local = code; local_msg = msg; } };
+    if (is_root && (!weights || !bias)) note(YOLO2_ERROR, "the root rank must pass the weight blobs");
+    else if (is_root && (n_weights < YOLO2_N_WEIGHTS || n_bias < YOLO2_N_BIAS)) note(YOLO2_ERROR, "weight blobs too small");
+    if (local == YOLO2_SUCCESS &&
+        (hipMalloc(&wd, wbytes) != hipSuccess || hipMalloc(&bd, bbytes) != hipSuccess || hipMalloc(&qd, qbytes) != hipSuccess))
+        note(YOLO2_MMAP_ERROR, "device buffers for the weight broadcast could not be allocated");
+    if (local == YOLO2_SUCCESS && is_root &&
+        (hipMemcpy(wd, weights, wbytes, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(bd, bias, bbytes, hipMemcpyHostToDevice) != hipSuccess ||
+         hipMemcpy(qd, qrec, qbytes, hipMemcpyHostToDevice) != hipSuccess))
+        note(YOLO2_DMA_ERROR, "H2D of the weight blobs failed");
+    (void)hipGetLastError();
+    // ---- agreement 1: does every rank have what the broadcast needs?
+    int agreed = 0;
+    int rc = agree_status(R, st->device, st->comm, st->stream, word, local, &agreed);
+    if (rc == YOLO2_SUCCESS && agreed != YOLO2_SUCCESS)
+        rc = local ? mfail(local, "%s", local_msg.c_str())
+                   : mfail(agreed, "another rank could not prepare the weight broadcast (status %d): no rank loads", agreed);
+    if (rc) { release(); return rc; }
+    // ---- the broadcast
     std::vector<Member> me(1);
     me[0].device = st->device; me[0].comm = st->comm; me[0].stream = st->stream;
     me[0].bufs = {wd, bd, qd};
-    int rc = bcast_blobs(me, {wbytes, bbytes, qbytes}, root);
-    if (rc == YOLO2_SUCCESS && hipMemcpy(qrec, qd, qbytes, hipMemcpyDeviceToHost) != hipSuccess) rc = mfail(YOLO2_DMA_ERROR, "D2H of the Q tables failed");
-    if (rc == YOLO2_SUCCESS) rc = load(wd, bd);
+    double ms = 0;
+    local = bcast_blobs(me, {wbytes, bbytes, qbytes}, root, &ms);
+    if (local) local_msg = yolo2_hip_last_error();
+    st->last_bcast_ms = ms; st->last_bcast_bytes = wbytes + bbytes + qbytes; st->bcasts++;
+    if (local == YOLO2_SUCCESS && hipMemcpy(qrec, qd, qbytes, hipMemcpyDeviceToHost) != hipSuccess) note(YOLO2_DMA_ERROR, "D2H of the Q tables failed");
+    if (local == YOLO2_SUCCESS && (local = load(wd, bd)) != YOLO2_SUCCESS) local_msg = yolo2_hip_last_error();
     (void)hipDeviceSynchronize();
+    // ---- agreement 2: did every rank load?
+    rc = agree_status(R, st->device, st->comm, st->stream, word, local, &agreed);
+    if (rc == YOLO2_SUCCESS && agreed != YOLO2_SUCCESS)
+        rc = local ? mfail(local, "%s", local_msg.c_str()) : mfail(agreed, "another rank failed to load the broadcast weights (status %d)", agreed);
     release();
     return rc;
 }
@@ -254,12 +357,12 @@ extern "C" int yolo2_hip_load_weights_int16_bcast(yolo2_hip_ctx *ctx, const int1
                                                   int n_bias_q, const int32_t *act_q, int n_act_q, int root)
 {
     int32_t rec[kQRec] = {0};
+    int local = YOLO2_SUCCESS;   // a root-side argument error is carried INTO the collective (load_bcast), not returned in front of it
     if (weights_reorg) {   // root
-        if (!weight_q || !bias_q || !act_q) return mfail(YOLO2_ERROR, "null Q table");
-        const int rc = pack_q(rec, weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
-        if (rc) return rc;
+        if (!weight_q || !bias_q || !act_q) local = mfail(YOLO2_ERROR, "null Q table");
+        else local = pack_q(rec, weight_q, n_weight_q, bias_q, n_bias_q, act_q, n_act_q);
     }
-    return load_bcast<int16_t>(ctx, weights_reorg, n_weights, bias, n_bias, rec, root, [&](void *wd, void *bd) {
+    return load_bcast<int16_t>(ctx, weights_reorg, n_weights, bias, n_bias, rec, local, root, [&](void *wd, void *bd) {
         return yolo2_hip_load_weights_int16_dev(ctx, (uint64_t)(uintptr_t)wd, YOLO2_N_WEIGHTS, (uint64_t)(uintptr_t)bd, YOLO2_N_BIAS, rec + 3,
                                                 rec[0], rec + 3 + 64, rec[1], rec + 3 + 128, rec[2]);
     });
@@ -269,7 +372,7 @@ extern "C" int yolo2_hip_load_weights_fp32_bcast(yolo2_hip_ctx *ctx, const float
                                                  size_t n_bias, int root)
 {
     int32_t rec[kQRec] = {0};
-    return load_bcast<float>(ctx, weights_reorg, n_weights, bias, n_bias, rec, root, [&](void *wd, void *bd) {
+    return load_bcast<float>(ctx, weights_reorg, n_weights, bias, n_bias, rec, YOLO2_SUCCESS, root, [&](void *wd, void *bd) {
         return yolo2_hip_load_weights_fp32_dev(ctx, (uint64_t)(uintptr_t)wd, YOLO2_N_WEIGHTS, (uint64_t)(uintptr_t)bd, YOLO2_N_BIAS);
     });
 }
@@ -282,6 +385,9 @@ struct yolo2_hip_multi {
     std::vector<ncclComm_t> comms;     // empty when there is a single device, or when a device is listed twice (no RCCL then)
     std::vector<hipStream_t> streams;
     bool duplicate = false;
+    double last_bcast_ms = 0;
+    size_t last_bcast_bytes = 0;
+    int bcasts = 0;
 };
 
 extern "C" int yolo2_hip_multi_create(const int *devices, int n_devices, yolo2_hip_multi **out)
@@ -337,6 +443,24 @@ extern "C" int yolo2_hip_multi_num_devices(yolo2_hip_multi *m) { return m ? (int
 extern "C" yolo2_hip_ctx *yolo2_hip_multi_ctx(yolo2_hip_multi *m, int i) { return m && i >= 0 && i < (int)m->ctx.size() ? m->ctx[(size_t)i] : nullptr; }
 extern "C" int yolo2_hip_multi_uses_rccl(yolo2_hip_multi *m) { return m && !m->comms.empty() ? 1 : 0; }
 
+extern "C" int yolo2_hip_multi_rccl_info(yolo2_hip_multi *m, yolo2_hip_rccl_info_t *out)
+{
+    if (!m || !out) return mfail(YOLO2_ERROR, "null argument");
+    if (m->comms.empty()) return mfail(YOLO2_ERROR, "this device list has no RCCL communicator (one device, or a device listed twice)");
+    const Rccl *R = rccl();
+    if (!R) return mfail(YOLO2_INIT_ERROR, "%s", g_rccl_err.c_str());
+    memset(out, 0, sizeof(*out));
+    RCCL_TRY(R->CommCount(m->comms[0], &out->nranks));
+    RCCL_TRY(R->CommUserRank(m->comms[0], &out->rank));
+    RCCL_TRY(R->CommCuDevice(m->comms[0], &out->device));
+    RCCL_TRY(R->GetVersion(&out->version));
+    out->bcasts = m->bcasts;
+    out->last_bcast_ms = m->last_bcast_ms;
+    out->last_bcast_bytes = (uint64_t)m->last_bcast_bytes;
+    snprintf(out->lib_path, sizeof(out->lib_path), "%s", R->path.c_str());
+    return YOLO2_SUCCESS;
+}
+
 // Blobs go host -> device 0, from there to every other device (ncclBroadcast; device-to-device copies when the list
 // has no communicator), then every context loads its own device copy.
 template <typename T, typename LoadFn>
@@ -363,7 +487,11 @@ static int multi_load(yolo2_hip_multi *m, const T *weights, size_t n_weights, co
             rc = mfail(YOLO2_DMA_ERROR, "H2D of the weight blobs failed");
     }
     if (rc == YOLO2_SUCCESS && n > 1) {
-        if (!m->comms.empty()) rc = bcast_blobs(mem, {wbytes, bbytes}, 0);
+        if (!m->comms.empty()) {
+            rc = bcast_blobs(mem, {wbytes, bbytes}, 0, &m->last_bcast_ms);
+            m->last_bcast_bytes = wbytes + bbytes;
+            m->bcasts++;
+        }
         else
             for (int i = 1; i < n && rc == YOLO2_SUCCESS; ++i)
                 for (int k = 0; k < 2; ++k)

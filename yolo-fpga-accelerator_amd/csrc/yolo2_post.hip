@@ -424,6 +424,17 @@ int postprocess(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, int final_q,
     if (std::is_same<T, short>::value && (final_q < -15 || final_q > 30)) return pfail(YOLO2_ERROR, "final Q %d out of range", final_q);
     const int device = yolo2_hip_ctx_device(ctx);
     HIPP_TRY(hipSetDevice(device), YOLO2_INIT_ERROR);
+    {   // The kernels run on the CONTEXT's device: a region tensor that lives in another GPU's HBM (e.g. allocated with the bare
+        // yolo2_hip_alloc while another device was current) would be read across xGMI at best and fault at worst.
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, (const void *)(uintptr_t)region_dev) != hipSuccess) {
+            (void)hipGetLastError();
+            return pfail(YOLO2_ERROR, "region tensor address %#llx is not device-accessible memory", (unsigned long long)region_dev);
+        }
+        if (attr.type == hipMemoryTypeDevice && attr.device != device)
+            return pfail(YOLO2_ERROR, "region tensor lives on device %d, the context runs on device %d (allocate it with yolo2_hip_alloc_on)",
+                         attr.device, device);
+    }
     hipStream_t st = (hipStream_t)stream;
     std::lock_guard<std::mutex> lk(g_call_mu);
     Luts l;

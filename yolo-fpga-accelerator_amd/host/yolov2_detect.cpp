@@ -389,7 +389,7 @@ void run_stream(AppConfig cfg)
             if (region_dev_frames < (size_t)n) {
                 if (region_dev) yolo2_hip_free(region_dev);
                 region_dev = 0;
-                if (yolo2_hip_alloc((size_t)n * YOLO2_REGION_ELEMS * sizeof(int16_t), &region_dev) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+                if (yolo2_hip_alloc_on(c0, (size_t)n * YOLO2_REGION_ELEMS * sizeof(int16_t), &region_dev) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
                 region_dev_frames = (size_t)n;
             }
             if (yolo2_hip_memcpy_h2d(region_dev, region.data(), (size_t)n * YOLO2_REGION_ELEMS * sizeof(int16_t)) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());

@@ -29,6 +29,27 @@ def exchange_unique_id(make_id, device: torch.device, src: int = 0) -> bytes:
     return bytes(t.cpu().numpy().tobytes())
 
 
+def all_ok(ok: bool, device: torch.device) -> bool:
+    """True on every rank iff `ok` on every rank (one tiny all-reduce).  Failure containment for a one-process-per-GPU
+    job: a rank whose local step failed must not leave the others blocked in the next barrier - every rank calls this
+    after each phase and all of them leave together when any of them failed."""
+    if not dist.is_initialized():
+        return bool(ok)
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()) == 1)
+
+
+def gather_row(values, device: torch.device):
+    """Every rank contributes a row of floats; every rank gets the [world][len] table (one all-gather)."""
+    row = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return row.cpu().numpy()[None, :]
+    out = [torch.empty_like(row) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, row)
+    return torch.stack(out).cpu().numpy()
+
+
 def pack_q_tables(weight_q, bias_q, act_q) -> torch.Tensor:
     """[n_wq, n_bq, n_aq, values...] as one int32 tensor of fixed length 3 + 3*64."""
     t = torch.zeros(3 + 3 * 64, dtype=torch.int32)

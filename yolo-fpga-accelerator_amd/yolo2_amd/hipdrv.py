@@ -40,6 +40,8 @@ EXPORTS = [
     "yolo2_hip_multi_uses_rccl", "yolo2_hip_multi_ctx", "yolo2_hip_multi_load_weights_int16", "yolo2_hip_multi_load_weights_fp32",
     "yolo2_hip_multi_run_frames_int16", "yolo2_hip_multi_run_images_u8_host", "yolo2_hip_rccl_unique_id",
     "yolo2_hip_rccl_init_rank", "yolo2_hip_rccl_finalize", "yolo2_hip_load_weights_int16_bcast", "yolo2_hip_load_weights_fp32_bcast",
+    "yolo2_hip_rccl_info", "yolo2_hip_multi_rccl_info", "yolo2_hip_ctx_device", "yolo2_hip_alloc_on",
+    "yolo2_hip_fp16_layer_kernel", "yolo2_hip_f16_store_check",
 ]
 
 
@@ -143,6 +145,13 @@ def lib():
     L.yolo2_hip_rccl_finalize.argtypes = [vp]
     L.yolo2_hip_load_weights_int16_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32, i32]
     L.yolo2_hip_load_weights_fp32_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i32]
+    L.yolo2_hip_rccl_info.argtypes = [vp, vp]
+    L.yolo2_hip_multi_rccl_info.argtypes = [vp, vp]
+    L.yolo2_hip_ctx_device.argtypes = [vp]
+    L.yolo2_hip_alloc_on.argtypes = [vp, C.c_size_t, C.POINTER(u64)]
+    L.yolo2_hip_fp16_layer_kernel.argtypes = [vp, i32]
+    L.yolo2_hip_fp16_layer_kernel.restype = C.c_char_p
+    L.yolo2_hip_f16_store_check.argtypes = [i32] * 12
     L.yolo2_get_status.restype = u32
     L.yolo2_read_reg.restype = u32
     L.yolo2_read_reg.argtypes = [u32]
@@ -470,11 +479,34 @@ def rccl_unique_id() -> bytes:
     return bytes(buf)
 
 
+class RcclInfo(C.Structure):
+    """yolo2_hip_rccl_info_t"""
+    _fields_ = [("nranks", C.c_int), ("rank", C.c_int), ("device", C.c_int), ("version", C.c_int), ("bcasts", C.c_int),
+                ("last_bcast_ms", C.c_double), ("last_bcast_bytes", C.c_uint64), ("lib_path", C.c_char * 256)]
+
+    def as_dict(self):
+        v = self.version
+        return {"nranks": self.nranks, "rank": self.rank, "device": self.device, "version": v,
+                "version_str": f"{v // 10000}.{v // 100 % 100}.{v % 100}" if v >= 10000 else str(v),
+                "bcasts": self.bcasts, "bcast_ms": self.last_bcast_ms, "bytes": int(self.last_bcast_bytes),
+                "lib_path": self.lib_path.decode()}
+
+
 class _BcastMixin:
     def rccl_init_rank(self, id128: bytes, nranks: int, rank: int):
         assert len(id128) == 128
         check(lib().yolo2_hip_rccl_init_rank(self._h, self.device, C.c_char_p(id128), nranks, rank), "yolo2_hip_rccl_init_rank")
         self._in_comm = True
+
+    def rccl_info(self) -> dict:
+        """What the library's communicator reports about itself (yolo2_hip_rccl_info)."""
+        info = RcclInfo()
+        check(lib().yolo2_hip_rccl_info(self._h, C.byref(info)), "yolo2_hip_rccl_info")
+        return info.as_dict()
+
+    def fp16_layer_kernels(self):
+        """Kernel name per layer of the fp16 launch table (after the first run at the current batch)."""
+        return {i: lib().yolo2_hip_fp16_layer_kernel(self._h, i).decode() for i in range(32) if lib().yolo2_hip_fp16_layer_kernel(self._h, i)}
 
     def rccl_finalize(self):
         if getattr(self, "_in_comm", False):
