@@ -294,10 +294,238 @@ def refapp_image():
     return np.clip(np.floor(f * 256.0), 0, 255).astype(np.uint8).transpose(1, 2, 0).copy()
 
 
+def _ref_decode(path):
+    """stbi_load(path, 3) of the reference's vendored stb, through its load_image_stb (src/core/yolo_image.cpp:167-189)."""
+    import ctypes
+    rh = orclib.ref_host()
+    rh.ref_load_image_u8.restype = ctypes.c_long
+    w, h = ctypes.c_int(0), ctypes.c_int(0)
+    cap = 2048 * 2048 * 3
+    rgb = np.zeros(cap, dtype=np.uint8)
+    chw = np.zeros(cap, dtype=np.float32)
+    n = rh.ref_load_image_u8(path.encode(), ctypes.byref(w), ctypes.byref(h), rgb.ctypes.data_as(ctypes.c_void_p),
+                             chw.ctypes.data_as(ctypes.c_void_p), ctypes.c_long(cap))
+    assert n == w.value * h.value * 3, (path, n)
+    return rgb[:n].reshape(h.value, w.value, 3).copy()
+
+
+def _png_bytes(pix, color, depth, interlace=False, filters=None, palette=None, trns=None, idat_split=0, level=6):
+    """A minimal PNG writer for the variants PIL cannot produce (Adam7, forced filter types, 16-bit RGB, 1/2/4-bit grey).
+    pix: [h][w][channels] integer samples (unscaled, < 2^depth)."""
+    import struct
+    import zlib
+    h, w, ch = pix.shape
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+    def pack_rows(sub):
+        hh, ww, _ = sub.shape
+        rows = []
+        for y in range(hh):
+            s = sub[y].reshape(-1).astype(np.int64)
+            if depth == 16:
+                b = np.stack([(s >> 8) & 255, s & 255], axis=1).reshape(-1).astype(np.uint8)
+            elif depth == 8:
+                b = s.astype(np.uint8)
+            else:
+                per = 8 // depth
+                pad = (-len(s)) % per
+                s = np.concatenate([s, np.zeros(pad, dtype=np.int64)]).reshape(-1, per)
+                b = np.zeros(len(s), dtype=np.int64)
+                for k in range(per):
+                    b |= s[:, k] << (8 - depth * (k + 1))
+                b = b.astype(np.uint8)
+            rows.append(b)
+        return rows
+
+    def filt(rows, bpp, fsel):
+        out = bytearray()
+        prev = np.zeros(len(rows[0]) if rows else 0, dtype=np.int64)
+        for y, r in enumerate(rows):
+            cur = r.astype(np.int64)
+            f = fsel[y % len(fsel)]
+            left = np.concatenate([np.zeros(bpp, dtype=np.int64), cur[:-bpp]]) if len(cur) > bpp else np.zeros(len(cur), dtype=np.int64)
+            if len(cur) > bpp:
+                ul = np.concatenate([np.zeros(bpp, dtype=np.int64), prev[:-bpp]])
+            else:
+                ul = np.zeros(len(cur), dtype=np.int64)
+            if f == 0:
+                d = cur
+            elif f == 1:
+                d = cur - left
+            elif f == 2:
+                d = cur - prev
+            elif f == 3:
+                d = cur - ((left + prev) >> 1)
+            else:
+                pp = left + prev - ul
+                pa, pb, pc = np.abs(pp - left), np.abs(pp - prev), np.abs(pp - ul)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, ul))
+                d = cur - pred
+            out.append(f)
+            out += (d & 255).astype(np.uint8).tobytes()
+            prev = cur
+        return bytes(out)
+
+    bpp = max(1, ch * depth // 8)
+    fsel = filters or [0]
+    if not interlace:
+        raw = filt(pack_rows(pix), bpp, fsel)
+    else:
+        raw = b""
+        for xo, yo, xs, ys in zip((0, 4, 0, 2, 0, 1, 0), (0, 0, 4, 0, 2, 0, 1), (8, 8, 4, 4, 2, 2, 1), (8, 8, 8, 4, 4, 2, 2)):
+            sub = pix[yo::ys, xo::xs]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filt(pack_rows(sub), bpp, fsel)
+    z = zlib.compress(raw, level)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
+    out += chunk(b"gAMA", struct.pack(">I", 45455))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    if idat_split:
+        for k in range(0, len(z), idat_split):
+            out += chunk(b"IDAT", z[k:k + idat_split])
+    else:
+        out += chunk(b"IDAT", z)
+    return out + chunk(b"tEXt", b"Comment\0synthetic") + chunk(b"IEND", b"")
+
+
+def gen_images():
+    """Inputs and expected outputs for the host's own JPEG / PNG decoders (host/y2_codec.cpp): (1) the reference's nine example
+    images (examples/test_images/*: the files' bytes are the input - data the reference ships for exactly this purpose), (2) small
+    synthetic encodings of every variant the decoder supports, written here with PIL / a minimal PNG writer.  Expected output in
+    both cases = the RGB bytes the compiled reference's stb (stbi_load(file, 3) inside load_image_stb) produces: the sha256 of all
+    of them and, for the small ones, the bytes themselves.  Data only."""
+    import hashlib
+    import io
+    from PIL import Image
+    out = {}
+    names = []
+
+    def add(name, data, tmpdir, ext, keep_rgb):
+        path = os.path.join(tmpdir, "img" + ext)
+        open(path, "wb").write(data)
+        rgb = _ref_decode(path)
+        out[f"{name}/file"] = np.frombuffer(data, dtype=np.uint8)
+        out[f"{name}/shape"] = np.array(rgb.shape[:2], dtype=np.int32)
+        out[f"{name}/sha256"] = np.frombuffer(hashlib.sha256(rgb.tobytes()).digest(), dtype=np.uint8)
+        if keep_rgb:
+            out[f"{name}/rgb"] = rgb
+        else:
+            out[f"{name}/rgb_rows"] = rgb[::41].copy()     # a sample for diagnostics; equality is asserted on the hash
+        names.append(name)
+        print(f"  {name:28s} {len(data):8d} B -> {rgb.shape[1]}x{rgb.shape[0]}")
+
+    tmp = tempfile.mkdtemp(prefix="y2img_")
+    try:
+        seen = {}
+        for f in sorted(os.listdir("/root/reference/examples/test_images")):
+            data = open(os.path.join("/root/reference/examples/test_images", f), "rb").read()
+            key = hashlib.sha256(data).hexdigest()
+            if key in seen:     # kite.jpg is a byte-identical copy of image2.jpg
+                out[f"ref/{f}/same_as"] = np.frombuffer(seen[key].encode(), dtype=np.uint8)
+                continue
+            seen[key] = f"ref/{f}"
+            add(f"ref/{f}", data, tmp, os.path.splitext(f)[1], keep_rgb=False)
+        # ---- synthetic pictures: smooth gradients + hard edges + noise, odd sizes (partial MCUs, 1-pixel-wide chroma rows)
+        rng = np.random.default_rng(20240607)
+
+        def picture(h, w):
+            yy, xx = np.mgrid[0:h, 0:w]
+            base = np.stack([128 + 100 * np.sin(xx / 7.0) * np.cos(yy / 5.0), (xx * 3 + yy * 5) % 256,
+                             255 * ((xx // 9 + yy // 6) % 2)], axis=2)
+            return np.clip(base + rng.normal(0, 12, size=(h, w, 3)), 0, 255).astype(np.uint8)
+
+        def jpeg(img, mode="RGB", **kw):
+            b = io.BytesIO()
+            Image.fromarray(img if mode != "L" else img[..., 1]).convert(mode).save(b, "JPEG", **kw)
+            return b.getvalue()
+
+        p1, p2, p3 = picture(61, 97), picture(33, 17), picture(1, 1)
+        for name, data in [
+            ("jpg/base_444", jpeg(p1, quality=90, subsampling=0)),
+            ("jpg/base_422", jpeg(p1, quality=75, subsampling=1)),
+            ("jpg/base_420", jpeg(p1, quality=60, subsampling=2)),
+            ("jpg/base_420_q100", jpeg(p1, quality=100, subsampling=2)),
+            ("jpg/base_420_q5", jpeg(p1, quality=5, subsampling=2)),
+            ("jpg/base_420_optimize", jpeg(p1, quality=80, subsampling=2, optimize=True)),
+            ("jpg/base_420_narrow", jpeg(p2, quality=85, subsampling=2)),
+            ("jpg/base_422_narrow", jpeg(p2, quality=85, subsampling=1)),
+            ("jpg/base_1x1", jpeg(p3, quality=85, subsampling=2)),
+            ("jpg/grey", jpeg(p1, mode="L", quality=80)),
+            ("jpg/grey_progressive", jpeg(p1, mode="L", quality=80, progressive=True)),
+            ("jpg/prog_444", jpeg(p1, quality=85, subsampling=0, progressive=True)),
+            ("jpg/prog_422", jpeg(p1, quality=70, subsampling=1, progressive=True)),
+            ("jpg/prog_420", jpeg(p1, quality=92, subsampling=2, progressive=True)),
+            ("jpg/prog_420_q20", jpeg(p1, quality=20, subsampling=2, progressive=True)),
+            ("jpg/prog_420_narrow", jpeg(p2, quality=85, subsampling=2, progressive=True)),
+            ("jpg/prog_1x1", jpeg(p3, quality=85, progressive=True)),
+            ("jpg/restart_blocks", jpeg(p1, quality=80, subsampling=2, restart_marker_blocks=3)),
+            ("jpg/restart_rows", jpeg(p1, quality=80, subsampling=0, restart_marker_rows=1)),
+            ("jpg/prog_restart", jpeg(p1, quality=80, subsampling=2, progressive=True, restart_marker_blocks=2)),
+            ("jpg/cmyk", jpeg(p1, mode="CMYK", quality=85)),
+            ("jpg/big_420", jpeg(picture(240, 323), quality=88, subsampling=2)),
+            ("jpg/big_prog", jpeg(picture(240, 323), quality=88, subsampling=2, progressive=True)),
+        ]:
+            add(name, data, tmp, ".jpg", keep_rgb=True)
+
+        def png(img, mode, **kw):
+            b = io.BytesIO()
+            im = Image.fromarray(img)
+            if mode == "P":
+                im = im.quantize(colors=kw.pop("colors", 200))
+            elif mode == "1":
+                im = im.convert("L").point(lambda v: 255 if v > 128 else 0).convert("1")
+            else:
+                im = im.convert(mode)
+            im.save(b, "PNG", **kw)
+            return b.getvalue()
+
+        rgba = np.concatenate([p1, rng.integers(0, 256, size=p1.shape[:2] + (1,), dtype=np.uint8)], axis=2)
+        g16 = (rng.integers(0, 65536, size=(23, 31, 1))).astype(np.int64)
+        rgb16 = (rng.integers(0, 65536, size=(23, 31, 3))).astype(np.int64)
+        pal = rng.integers(0, 256, size=(16, 3), dtype=np.uint8)
+        for name, data in [
+            ("png/rgb", png(p1, "RGB")),
+            ("png/rgba", png(rgba, "RGBA")),
+            ("png/grey", png(p1, "L")),
+            ("png/grey_alpha", png(rgba, "LA")),
+            ("png/palette", png(p1, "P")),
+            ("png/palette_16", png(p1, "P", colors=16)),
+            ("png/palette_2", png(p1, "P", colors=2)),
+            ("png/bilevel", png(p1, "1")),
+            ("png/rgb_level0", png(p1, "RGB", compress_level=0)),
+            ("png/rgb_level9", png(picture(120, 160), "RGB", compress_level=9)),
+            ("png/rgb16", _png_bytes(rgb16, 2, 16, filters=[0, 1, 2, 3, 4])),
+            ("png/grey16_interlaced", _png_bytes(g16, 0, 16, interlace=True, filters=[4, 3])),
+            ("png/rgb16_trns", _png_bytes(rgb16, 2, 16, trns=bytes([0, 1, 0, 2, 0, 3]))),
+            ("png/grey4", _png_bytes(g16 % 16, 0, 4, filters=[1, 2])),
+            ("png/grey2_interlaced", _png_bytes(g16 % 4, 0, 2, interlace=True)),
+            ("png/grey1", _png_bytes(g16 % 2, 0, 1, filters=[0, 2])),
+            ("png/grey8_trns", _png_bytes(g16 % 256, 0, 8, trns=bytes([0, 77]))),
+            ("png/pal4_interlaced", _png_bytes(g16 % 16, 3, 4, interlace=True, palette=pal, trns=bytes(range(0, 160, 10)))),
+            ("png/pal1", _png_bytes(g16 % 2, 3, 1, palette=pal[:2])),
+            ("png/rgb_interlaced", _png_bytes(p1.astype(np.int64), 2, 8, interlace=True, filters=[0, 1, 2, 3, 4], idat_split=97)),
+            ("png/rgba_interlaced_tiny", _png_bytes(rgba[:3, :5].astype(np.int64), 6, 8, interlace=True, filters=[4])),
+            ("png/rgb_filters", _png_bytes(p1.astype(np.int64), 2, 8, filters=[4, 3, 2, 1, 0], idat_split=1000)),
+            ("png/grey_alpha16", _png_bytes(rng.integers(0, 65536, size=(9, 14, 2)).astype(np.int64), 4, 16, filters=[3])),
+            ("png/one_pixel", _png_bytes(np.array([[[200, 100, 50]]], dtype=np.int64), 2, 8)),
+        ]:
+            add(name, data, tmp, ".png", keep_rgb=True)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "images.npz"), **out)
+    print("wrote images.npz:", len(names), "images,", os.path.getsize(os.path.join(HERE, "images.npz")), "bytes")
+
+
 if __name__ == "__main__":
     if not orclib.have_ref():
         sys.exit("oracle/_ref is not built: run `make -C oracle ref` in the build container")
-    what = sys.argv[1:] or ["kats", "fullnet", "host", "dog", "refapp"]
+    what = sys.argv[1:] or ["kats", "fullnet", "host", "dog", "refapp", "images"]
     if "kats" in what:
         gen_kats()
     if "fullnet" in what:
@@ -308,3 +536,5 @@ if __name__ == "__main__":
         gen_dog()
     if "refapp" in what:
         gen_refapp()
+    if "images" in what:
+        gen_images()

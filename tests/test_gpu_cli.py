@@ -1,6 +1,7 @@
 """GPU test of the repo's own CLI: yolov2_detect --backend hip end to end (PPM in, weight files in
 the reference's on-disk formats, region dumps + boxes out), checked against the library driven
 from Python on the same letterboxed frame and against the reference-derived host fixtures."""
+import json
 import os
 import subprocess
 
@@ -186,3 +187,38 @@ def test_cli_streaming_list_dir_video_jsonl(tmp_path):
     recs = [json.loads(l) for l in out.read_text().splitlines()]
     assert [(x["mode"], x["frame_index"], x["inference_index"]) for x in recs] == [("video", 1, 1), ("video", 3, 2)]
     assert recs[0]["detections"] == single[2]["detections"]
+
+
+def test_cli_dog_jpg_end_to_end_reproduces_c1_fixture(tmp_path):
+    """configs[0] (C1) from the FILE: the reference's examples/test_images/dog.jpg (its bytes travel in tests/golden/images.npz) through
+    `yolov2_detect --input dog.jpg` - own JPEG decoder, own letterbox, GPU network - gives the region tensors the compiled reference's
+    yolov2_hls_ps produced from the same file (tests/golden/dog.npz), int16 bit for bit and fp32 bit for bit; a list mixing the JPEG,
+    a PNG and a progressive re-encoding runs through the streaming frontend."""
+    images = np.load(os.path.join(orclib.ROOT, "tests", "golden", "images.npz"))
+    dog = np.load(os.path.join(orclib.ROOT, "tests", "golden", "dog.npz"))
+    jpg = tmp_path / "dog.jpg"
+    jpg.write_bytes(images["ref/dog.jpg/file"].tobytes())
+    model = synth.SynthModel(seed=1)
+    model.write_files(str(tmp_path / "weights"), fp32=True, int16=True)
+    for prec, key, dt in (("int16", "i16/region_raw_i16", None), ("fp32", "f32/region_raw_f32", np.float32)):
+        env = dict(os.environ, YOLO2_DUMP_REGION_RAW=str(tmp_path / f"raw_{prec}.txt"), YOLO2_DUMP_REGION=str(tmp_path / f"proc_{prec}.txt"))
+        r = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names"),
+                            "--weights", str(tmp_path / "weights"), "--input", str(jpg), "--output", str(tmp_path / f"pred_{prec}"),
+                            "--thresh", "0.05", "--backend", "hip", "--precision", prec],
+                           capture_output=True, text=True, env=env, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "(w=768, h=576, c=3)" in r.stdout
+        raw = np.loadtxt(tmp_path / f"raw_{prec}.txt")
+        if prec == "int16":
+            q = int(dog["i16/final_q"])
+            assert np.array_equal(np.rint(raw * (1 << q)).astype(np.int64), dog[key].reshape(-1).astype(np.int64))
+        else:
+            assert np.array_equal(raw.astype(np.float32).view(np.uint32), dog[key].reshape(-1).view(np.uint32))
+    # streaming frontend over mixed formats
+    (tmp_path / "t.png").write_bytes(images["ref/test1.png/file"].tobytes())
+    (tmp_path / "p.jpg").write_bytes(images["jpg/big_prog/file"].tobytes())
+    lst = tmp_path / "list.txt"
+    lst.write_text(f"{jpg}\n{tmp_path / 't.png'}\n{tmp_path / 'p.jpg'}\n")
+    r = _run(["--weights", str(tmp_path / "weights"), "--input-list", str(lst), "--batch", "2", "--thresh", "0.05", "--jsonl", str(tmp_path / "o.jsonl")], tmp_path)
+    recs = [json.loads(l) for l in open(tmp_path / "o.jsonl")]
+    assert [(x["width"], x["height"]) for x in recs] == [(768, 576), (216, 216), (323, 240)]

@@ -427,7 +427,9 @@ int postprocess(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, int final_q,
     {   // The kernels run on the CONTEXT's device: a region tensor that lives in another GPU's HBM (e.g. allocated with the bare
         // yolo2_hip_alloc while another device was current) would be read across xGMI at best and fault at worst.
         hipPointerAttribute_t attr;
-        if (hipPointerGetAttributes(&attr, (const void *)(uintptr_t)region_dev) != hipSuccess) {
+        // (ordinary host memory is reported as hipMemoryTypeUnregistered with hipSuccess on ROCm 6+, as an error before)
+        if (hipPointerGetAttributes(&attr, (const void *)(uintptr_t)region_dev) != hipSuccess ||
+            (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged)) {
             (void)hipGetLastError();
             return pfail(YOLO2_ERROR, "region tensor address %#llx is not device-accessible memory", (unsigned long long)region_dev);
         }

@@ -44,6 +44,13 @@ struct ImageU8 {
     std::vector<uint8_t> rgb;   // [h][w][3]
 };
 ImageU8 load_pnm_u8(const std::string &path);
+// The host's own JPEG (baseline, extended-sequential, progressive) and PNG decoders (y2_codec.cpp): the bytes stbi_load(file, 3)
+// of the reference's vendored stb_image v2.19 hands load_image_stb (src/core/yolo_image.cpp:167-189), reproduced byte for byte.
+ImageU8 decode_jpeg(const uint8_t *data, size_t n);       // throw std::runtime_error
+ImageU8 decode_png(const uint8_t *data, size_t n);
+ImageU8 decode_image(const uint8_t *data, size_t n, const std::string &name);   // by signature
+ImageU8 load_image_u8(const std::string &path);           // JPEG / PNG / binary PNM by signature
+Image load_image(const std::string &path);                // load_image_stb(path, 3): + bytes / 255 into CHW floats
 void save_ppm(const Image &im, const std::string &path);
 Image resize_image(const Image &im, int w, int h);        // yolo_image.cpp:84-126 (two-pass bilinear)
 Image letterbox_image(const Image &im, int w, int h);     // yolo_image.cpp:148-165 (grey 0.5 bars)

@@ -91,4 +91,16 @@ int y2h_load_pnm(const char *path, int *whc, float *out, long capacity)
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return -1; }
 }
+
+// decode_image (y2_codec.cpp): JPEG / PNG bytes -> RGB bytes [h][w][3]; returns w*h*3, or -1 (y2h_last_error) / -2 (capacity)
+long y2h_decode_image(const unsigned char *data, long n, int *w, int *h, unsigned char *rgb, long cap)
+{
+    try {
+        const ImageU8 im = decode_image(data, (size_t)n, "<memory>");
+        *w = im.w; *h = im.h;
+        if ((long)im.rgb.size() > cap) return -2;
+        memcpy(rgb, im.rgb.data(), im.rgb.size());
+        return (long)im.rgb.size();
+    } catch (const std::exception &e) { g_err = e.what(); return -1; }
+}
 }

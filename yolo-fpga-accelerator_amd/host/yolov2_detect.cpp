@@ -6,7 +6,8 @@
 // (include/yolo2_hip.h); there is no CPU backend here -- `--backend hls|cpu` names the reference's
 // own binaries and is rejected with a pointer to them.
 //
-// Differences that are deliberate: images are binary PPM/PGM (tools/img2ppm.py converts JPEG/PNG),
+// Differences that are deliberate: images are decoded by the host's own JPEG / PNG decoder (y2_codec.cpp: the bytes the
+// reference's stb_image produces, reproduced byte for byte; binary PPM/PGM are read too),
 // the annotated result is written as PPM, boxes are also printed as text and (--json) JSON lines;
 // `--batch N` runs the same frame N times through one batched call to show the batched entry.
 //
@@ -40,7 +41,7 @@ namespace {
 struct AppConfig {
     std::string cfg_path = "config/yolov2.cfg";
     std::string names_path = "config/coco.names";
-    std::string input_path = "examples/test_images/dog.ppm";
+    std::string input_path = "examples/test_images/dog.jpg";
     std::string weights_dir = "weights";
     std::string output_prefix;
     float thresh = 0.25f;  // the reference's code default (its usage text says 0.5: yolov2_main.cpp:36,69)
@@ -64,10 +65,10 @@ struct AppConfig {
 void print_usage(const char *prog)
 {
     std::printf(
-        "Usage: %s [options] [image.ppm]\n"
+        "Usage: %s [options] [image]\n"
         "  --cfg <path>          Network cfg file (default: config/yolov2.cfg)\n"
         "  --names <path>        Class names file (default: config/coco.names)\n"
-        "  --input <path>        Input image, binary PPM/PGM\n"
+        "  --input <path>        Input image: JPEG (baseline / progressive), PNG, or binary PPM/PGM\n"
         "  --weights <dir>       Directory with weights_reorg_int16.bin, bias_int16.bin, *_Q.bin (default: weights)\n"
         "  --output <prefix>     Output file prefix without extension (default: results/<input>_prediction)\n"
         "  --thresh <float>      Confidence threshold (default: 0.25)\n"
@@ -81,8 +82,8 @@ void print_usage(const char *prog)
         "  --devices <a,b,..>    Several HIP devices: frames shard contiguously, weights are broadcast once (RCCL)\n"
         "  --json                Also print detections as JSON lines\n"
         "streaming (frames in chunks of --batch per device, bytes to the GPU, letterbox + network + NMS there):\n"
-        "  --input-list <file>   One PPM/PGM path per line\n"
-        "  --input-dir <dir>     Every *.ppm / *.pgm of a directory, sorted by name\n"
+        "  --input-list <file>   One image path per line\n"
+        "  --input-dir <dir>     Every *.jpg / *.jpeg / *.png / *.ppm / *.pgm of a directory, sorted by name\n"
         "  --video-raw <file|->  Raw RGB24 frames (e.g. from `ffmpeg -f rawvideo -pix_fmt rgb24 -`), with\n"
         "  --video-width <w> --video-height <h>   frame size (default 640x480)\n"
         "  --max-frames <n>      Stop after n inference frames (default: all)\n"
@@ -270,7 +271,7 @@ class FrameSource {
         } else if (!cfg.input_dir.empty()) {
             for (const auto &e : fs::directory_iterator(cfg.input_dir)) {
                 const std::string ext = e.path().extension().string();
-                if (ext == ".ppm" || ext == ".pgm") files_.push_back(e.path().string());
+                if (ext == ".ppm" || ext == ".pgm" || ext == ".jpg" || ext == ".jpeg" || ext == ".png") files_.push_back(e.path().string());
             }
             std::sort(files_.begin(), files_.end());
             mode_ = "dir";
@@ -302,7 +303,7 @@ class FrameSource {
             const bool take = (count_ % cfg_.infer_every) == 0;
             ++count_;
             if (mode_ != "video") {
-                if (take) f.img = y2h::load_pnm_u8(files_[pos_]);
+                if (take) f.img = y2h::load_image_u8(files_[pos_]);
                 ++pos_;
             }
             if (!take) continue;
@@ -468,7 +469,7 @@ void run_detector(AppConfig cfg)
     const y2h::Network net = y2h::parse_cfg(cfg.cfg_path);
     check_topology(net);
     const std::vector<std::string> names = y2h::load_names(cfg.names_path);
-    y2h::Image im = y2h::load_pnm(cfg.input_path);
+    y2h::Image im = y2h::load_image(cfg.input_path);   // load_image_stb(path, 3) of the reference, own decoders
     std::printf("Input img: %s (w=%d, h=%d, c=%d)\n", cfg.input_path.c_str(), im.w, im.h, im.c);
     const y2h::Image sized = y2h::letterbox_image(im, net.w, net.h);
 
