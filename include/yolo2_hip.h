@@ -331,6 +331,21 @@ int yolo2_hip_postprocess_f32(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch
                               float thresh, float nms, yolo2_hip_det *dets, int cap_per_frame, int *counts,
                               float *rows, int *totals, float *proc, void *stream);
 
+/* The whole chain for camera-style input at the path's rate: n images of arbitrary sizes as HOST bytes -> detection records, in
+ * chunks of `batch` images.  Bytes cross PCIe in, letterboxing and the network run on the GPU, the region tensor STAYS in HBM and
+ * the tail (region + boxes + NMS + record compaction) runs on the same device right behind the network; only the records (32 bytes
+ * each) and the per-frame counts come back.  Upload, kernels and download of consecutive chunks overlap on three HIP streams.
+ * What the reference's streaming loop does frame by frame on the CPU (linux_app/src/main.c:878-1288: yolo2_run_inference +
+ * yolo2_forward_region_layer / get_region_detections / do_nms_sort per frame).
+ *   flags   YOLO2_DETS_BEST_CLASS: one record per detection - its best class (linux_app/src/main.c:1040-1052); a frame then has at
+ *           most 845 records, so cap_per_frame = 845 never truncates.  0: a record per (detection, class) with prob > 0.
+ *   dets    [n][cap_per_frame]; counts[f] = records frame f produced (if > cap_per_frame the surplus was dropped); dets[].frame is the
+ *           image's index in `images`.  Records identical to yolo2_hip_postprocess_int16's on the same tensors.  Synchronous. */
+#define YOLO2_DETS_BEST_CLASS 1
+int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *ctx, const uint8_t *const *images, const int *widths, const int *heights,
+                                 int channels, int n, int batch, float thresh, float nms, int flags, yolo2_hip_det *dets,
+                                 int cap_per_frame, int *counts, int *final_q);
+
 /* ------------------------------------------------------- multi-GPU: frame sharding, one weight broadcast
  *
  * SURVEY.md 8(b) "init(device_list) ... load_weights (H2D on rank 0, RCCL broadcast to the rest)", 8(e): frames are
@@ -363,6 +378,12 @@ int  yolo2_hip_multi_run_frames_int16(yolo2_hip_multi *m, const float *frames, i
 int  yolo2_hip_multi_run_images_u8_host(yolo2_hip_multi *m, const uint8_t *const *images, const int *widths,
                                         const int *heights, int channels, int n, int batch_per_device,
                                         int16_t *region_host, int *final_q);
+
+/* images -> detection records, shard i on device i: network AND tail run on the device that owns the shard (no region tensor
+ * travels to the host or to device 0); see yolo2_hip_run_images_u8_dets. */
+int  yolo2_hip_multi_run_images_u8_dets(yolo2_hip_multi *m, const uint8_t *const *images, const int *widths, const int *heights,
+                                        int channels, int n, int batch_per_device, float thresh, float nms, int flags,
+                                        yolo2_hip_det *dets, int cap_per_frame, int *counts, int *final_q);
 
 /* (b) one process per device (torchrun / MPI style; what bench.py --gpus N runs): rank 0 makes the 128-byte id
  * (ncclGetUniqueId), the launcher hands it to every rank, each rank joins with its context (ncclCommInitRank), then

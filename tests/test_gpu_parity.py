@@ -262,6 +262,34 @@ def test_fullnet_every_tile_shape_and_form(P, path, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("P", [1, 2])
+@pytest.mark.parametrize("path", ["3", "4"])
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_sixteen_channels_per_wavefront(qset, path, P, monkeypatch):
+    """k_conv_i16_w16 (two wavefronts of 16 output channels per workgroup, round 3) forced on every 3x3 layer where it is legal,
+    both packed forms, both tile shapes, both Q sets, 5 frames (tiles straddle frames; ragged last tile): bit-exact against the
+    reference fixture and the oracle."""
+    monkeypatch.setenv("YOLO2_FORCE_P", str(P))
+    monkeypatch.setenv("YOLO2_FORCE_PATH", path)
+    monkeypatch.setenv("YOLO2_FORCE_W16", "1")
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 5, 3), synth.frames(fseed, 1)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    ctx.set_batch(5)
+    blocks = [ctx.conv_launch_info(l.ord)["block"] for l in net.CONVS]
+    assert sum(b == 128 for b in blocks) >= 13, blocks          # the 3x3 layers whose blocks all run a packed form
+    assert all(b == 256 for l, b in zip(net.CONVS, blocks) if l.size == 1)
+    region, _ = ctx.run_batch_host(frames)
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    assert np.array_equal(region[0], want) and np.array_equal(region[4], want)
+    orclib.oracle().orc_set_threads(16)
+    ri, _, _ = orclib.forward_i16(model, frames[2])
+    assert np.array_equal(region[2].reshape(-1), ri)
+    ctx.close()
+
+
 @pytest.mark.parametrize("path", [None, "0"])
 @pytest.mark.parametrize("qset", ["std", "varq"])
 def test_fullnet_split_k(qset, path, monkeypatch):

@@ -247,3 +247,47 @@ def test_c5_batch2048_sharded_over_eight_contexts_on_one_gpu():
     assert q == q0 and got.shape == (2048, 425, 13, 13)
     g = got.reshape(256, 8, -1)
     assert np.array_equal(g, np.broadcast_to(want.reshape(1, 8, -1), g.shape))
+
+
+def test_images_to_detections_entry_keeps_the_region_tensor_on_the_device():
+    """yolo2_hip_run_images_u8_dets (round 3): bytes in -> letterbox + network + region / boxes / NMS + record compaction on the device,
+    chunks overlapped on three streams; its records must be exactly those of the two-step route (region tensors to the host, uploaded
+    again, yolo2_hip_postprocess_int16) - all classes, and the best-class mode the streaming CLI uses; through one context (chunks
+    of 2 and 3 with a ragged last chunk) and through the multi entry (two shards on device 0)."""
+    model = synth.SynthModel(seed=1)
+    rgb = DOG["rgb"]
+    imgs = [rgb, rgb[::2, ::2].copy(), rgb[:, ::-1].copy(), rgb[100:400, 50:700].copy(), rgb.transpose(1, 0, 2).copy(), rgb[::3, ::2].copy(),
+            rgb[:300].copy()]
+    thresh, nms = 0.05, 0.45
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    region, q = ctx.run_images_host(imgs, batch=3)
+    buf = hipdrv.DevBuf(region)
+    ws, hs = [im.shape[1] for im in imgs], [im.shape[0] for im in imgs]
+    want = hipdrv.postprocess(ctx, buf.addr, len(imgs), ws, hs, thresh, nms, final_q=q, cap=4096)
+    buf.free()
+    assert min(int(c) for c in want["counts"]) > 5
+    for batch in (2, 3):
+        got = hipdrv.run_images_dets(ctx._h, imgs, batch, thresh, nms, cap=4096, best_class=False)
+        assert got["final_q"] == q and np.array_equal(got["counts"], want["counts"])
+        for f in range(len(imgs)):
+            assert np.array_equal(got["dets"][f], want["dets"][f]), (batch, f)
+    # best-class mode: one record per detection, its best class, first among equals
+    best = hipdrv.run_images_dets(ctx._h, imgs, 3, thresh, nms, cap=845, best_class=True)
+    for f in range(len(imgs)):
+        w = want["dets"][f]
+        exp = []
+        for det in np.unique(w["det"]):       # records are grouped by detection, classes ascending
+            rows = w[w["det"] == det]
+            exp.append(rows[np.argmax(rows["prob"])])
+        exp = np.array(exp, dtype=w.dtype)
+        assert int(best["counts"][f]) == len(exp) <= 845
+        assert np.array_equal(best["dets"][f], exp), f
+    ctx.close()
+    m = hipdrv.Yolo2HipMulti([0, 0])
+    m.load_model(model)
+    gm = hipdrv.run_images_dets(m._m, imgs, 2, thresh, nms, cap=845, best_class=True, multi=True)
+    m.close()
+    assert np.array_equal(gm["counts"], best["counts"])
+    for f in range(len(imgs)):
+        assert np.array_equal(gm["dets"][f], best["dets"][f]), f

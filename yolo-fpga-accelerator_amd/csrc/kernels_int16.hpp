@@ -168,6 +168,11 @@ __device__ __forceinline__ long step64(long acc, int2 x, int2 w, const ConvArgs 
 #ifndef PREX_MAX_P
 #define PREX_MAX_P 2
 #endif
+#ifndef Y2_I16_ABL
+#define Y2_I16_ABL 0   // diagnostic builds only (tools/build_variant.sh): 1 = every group re-reads group 0's weight slice (scalar-cache hits:
+                       // what the per-tap scalar loads cost), 2 = no input staging inside the loop, 4 = no workgroup barrier inside the loop.
+                       // Results are wrong with any of them; only the timing is of interest.
+#endif
 template <int KS, int P, int MODE, int NST, int GRP = 1>
 __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in, int2 *__restrict__ out,
                                                    const int2 *__restrict__ wpk,
@@ -275,11 +280,13 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     for (int cg = 0; cg < niter; ++cg) {
         // branch-free: the last group re-fetches its own tile instead of testing `cg + 1 < niter`
         src += (cg + 1 < niter) ? a.in_cg_stride * GRP : 0;
+#if !(Y2_I16_ABL & 2)
 #pragma unroll
         for (int k = 0; k < NST; ++k) {
             const int i = tid + k * 256;
             if (i < LtG) stage[k] = src[src_off(i)];
         }
+#endif
         const char *tile = lds_b + (cg & 1) * buf_items * 8;
         // Small tiles (P <= 2): fetch the whole group's input values up front, so the LDS latency of a
         // tap is not exposed when few wavefronts are resident (the tail of a launch at modest batch).
@@ -336,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             if (MODE == 0) __builtin_amdgcn_sched_barrier(0);
         }
         }
+#if !(Y2_I16_ABL & 2)
         {
             int2 *nxt = lds + ((cg + 1) & 1) * buf_items;
 #pragma unroll
@@ -344,8 +352,15 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
                 if (i < LtG) nxt[lds_off(i)] = stage[k];
             }
         }
+#endif
+#if !(Y2_I16_ABL & 1)
         wq += KK * 32;
+#else
+        asm volatile("" : "+s"(wq));
+#endif
+#if !(Y2_I16_ABL & 4)
         __syncthreads();
+#endif
     }
 
     // write-back with integer leaky (core_compute.cpp:175-264): 2 items (8 channels) per pixel
@@ -367,6 +382,146 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
                 }
                 v[t] = a.leaky ? leaky_i16(e) : e;
             }
+            int2 o;
+            o.x = (v[0] & 0xffff) | (v[1] << 16);
+            o.y = (v[2] & 0xffff) | (v[3] << 16);
+            if (valid[p]) dst[fo[p]] = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ 16 output channels per wavefront (2-wave workgroups)
+//
+// Ablation of k_conv_i16 at batch 256 (profiles/r03_i16_ablation_b256.txt): removing the barrier changes nothing, removing the
+// input staging gains 1 % on the 3x3 layers - what is left between its ~93 % and the issue ceiling is SIMD time of the NON-step
+// instructions of a wavefront: above all the ds_read of the input items (9 x P reads of 8 bytes per lane and channel group) and
+// the per-tap wait for its scalar weight load, both of which scale with the number of (pixel, tap) pairs a wavefront visits, not
+// with the steps it does there.  The conv + pool kernel, whose four pixels share a 4 x 4 patch (16 reads for 36 taps), runs the
+// same layer shapes at 95.5 %.  Here a wavefront owns SIXTEEN output channels instead of eight: every input item read from LDS
+// and every visit of a tap feeds two 8-channel step sequences (the second with the next 16 SGPRs of the same 32-channel weight
+// slice), i.e. half the LDS reads, half the staged bytes per step and twice the work behind every scalar-load wait.  The
+// workgroup stays one 32-channel block x 64 P pixels - it is two wavefronts instead of four, sixteen of them per CU - so grids,
+// the block-wise arithmetic forms, the XCD numbering and the tile geometry are those of k_conv_i16.  Forms C / D only.
+template <int KS, int P, int MODE, int NST>
+__global__ __launch_bounds__(128, 4) void k_conv_i16_w16(const int2 *__restrict__ in, int2 *__restrict__ out, const int2 *__restrict__ wpk,
+                                                          const short *__restrict__ bias, const ConvArgs a)
+{
+    static_assert(MODE == 3 || MODE == 4, "packed-accumulator forms only");
+    extern __shared__ int2 lds[];
+    constexpr int T = 64 * P, KT = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // 0 / 1: channels [16 wave, 16 wave + 16) of the block
+    int tile = blockIdx.x, yb = blockIdx.y;
+    if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
+    const int mb = a.mb_list ? a.mb_list[yb] : yb;
+    const int q0 = tile * T, qlast = min(q0 + T, a.npix) - 1;
+    const int halo = (KS == 3) ? a.Wp + 1 : 0;
+    const int fmin = flat_of(a, q0), fmax = flat_of(a, qlast);
+    const int tile_start = fmin - halo;
+    const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
+
+    int fo[P], rowaddr[P][KS];
+    bool valid[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int q = q0 + p * 64 + lane;
+        valid[p] = q <= qlast;
+        fo[p] = flat_of(a, min(q, qlast));
+        const int lo = fo[p] - tile_start;
+#pragma unroll
+        for (int i = 0; i < KS; ++i) rowaddr[p][i] = (KS == 3) ? (lo + (i - 1) * a.Wp - 1) * 8 : lo * 8;
+    }
+    int acc[P][8];    // [pixel][channel pair]: pairs 0-3 = channels 0-7 of this wavefront, pairs 4-7 = channels 8-15
+    {
+        const short *bp = bias + mb * 32 + wave * 16;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int b2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int b = bp[2 * j + h];
+                b2[h] = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
+            }
+            const int pk = (b2[0] & 0xffff) | (b2[1] << 16);   // the host proved |shifted bias| <= 32767
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p][j] = pk;
+        }
+    }
+    int r_vgpr = a.round;
+    asm volatile("" : "+v"(r_vgpr));
+    const int s = a.shift;
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    const int2 *src = in + kLead + tile_start;
+    const int2 *wq = wpk + ((long)mb * a.CGin * KT * 32 + wave * 16);   // [mb][cg][tap][32]
+
+    int2 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 128;
+        if (i < Lt) stage[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 128;
+        if (i < Lt) lds[i] = stage[k];
+    }
+    __syncthreads();
+
+    for (int cg = 0; cg < a.CGin; ++cg) {
+        src += (cg + 1 < a.CGin) ? a.in_cg_stride : 0;     // branch-free: the last group re-fetches its own tile
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 128;
+            if (i < Lt) stage[k] = src[i];
+        }
+        const char *tl = lds_b + (cg & 1) * a.lt_max * 8;
+        int2 xv[KT][P];
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt)
+#pragma unroll
+            for (int p = 0; p < P; ++p) xv[tt][p] = *reinterpret_cast<const int2 *>(tl + rowaddr[p][tt / KS] + (tt % KS) * 8);
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {       // the two 8-channel halves take their 16 SGPRs one after the other
+                int2 w[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) w[m] = wq[tt * 32 + h * 8 + m];   // wave-uniform: scalar loads
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (MODE == 4) {
+                        stepD8(acc[p][4 * h], acc[p][4 * h + 1], acc[p][4 * h + 2], acc[p][4 * h + 3], xv[tt][p], w, r_vgpr, 0x07060302);
+                    } else {
+                        stepC4(acc[p][4 * h], acc[p][4 * h + 1], xv[tt][p], w[0], w[1], w[2], w[3], r_vgpr, s);
+                        stepC4(acc[p][4 * h + 2], acc[p][4 * h + 3], xv[tt][p], w[4], w[5], w[6], w[7], r_vgpr, s);
+                    }
+                }
+            }
+        }
+        {
+            int2 *nxt = lds + ((cg + 1) & 1) * a.lt_max;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int i = tid + k * 128;
+                if (i < Lt) nxt[i] = stage[k];
+            }
+        }
+        wq += KT * 32;
+        __syncthreads();
+    }
+
+    // write-back with integer leaky: 4 items (16 channels) per pixel
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int cgo = mb * 8 + wave * 4 + g;
+        if (cgo >= a.CGout) continue;
+        int2 *dst = out + a.out_base + (long)cgo * a.out_cg_stride;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int p01 = acc[p][2 * g], p23 = acc[p][2 * g + 1];
+            int v[4] = {(int)(short)(p01 & 0xffff), p01 >> 16, (int)(short)(p23 & 0xffff), p23 >> 16};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = a.leaky ? leaky_i16(v[t]) : v[t];
             int2 o;
             o.x = (v[0] & 0xffff) | (v[1] << 16);
             o.y = (v[2] & 0xffff) | (v[3] << 16);

@@ -65,6 +65,7 @@ struct ConvPlan {
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
     int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
     int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
+    int w16 = 0;               // 1: k_conv_i16_w16 - two wavefronts of 16 output channels each per workgroup instead of four of 8
     int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
     int pool_fused = 0;        // conv + leaky + 2x2 pool in one kernel (k_conv_i16_pool): 1 = pooled tensor only, 2 = + full tensor
     int lds_pad = 0;           // extra dynamic LDS requested only to cap workgroups per CU (autotuned):
@@ -82,6 +83,16 @@ struct Tensor {
     int2 *d = nullptr;
 };
 
+// Device buffers of one post-processing call in flight (yolo2_post.hip)
+struct Y2PostBufs {
+    int cap_frames = 0;
+    size_t cap_dets = 0;
+    float *rows = nullptr, *rows2 = nullptr;
+    int *totals = nullptr, *counts = nullptr;
+    void *geom = nullptr;            // [cap_frames] letterbox-correction records (y2_post_geom_bytes() each)
+    yolo2_hip_det *dets = nullptr;   // [cap_frames][cap]
+};
+
 // Staging for the host-buffer entries (run_frames / run_images): two buffer sets and three streams
 // (upload, kernels, download), kept with the context and grown on demand so that a caller streaming
 // chunk after chunk does not pay pinned-memory allocation per call.
@@ -93,6 +104,12 @@ struct PipeBufs {
     int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
     hipEvent_t e_in[2] = {nullptr, nullptr}, e_run[2] = {nullptr, nullptr}, e_out[2] = {nullptr, nullptr};
+    // the tail as a pipeline stage (yolo2_hip_run_images_u8_dets): per buffer set its device buffers and pinned host mirrors
+    int post_batch = 0, post_cap = 0;
+    Y2PostBufs post[2];
+    uint8_t *hgeom[2] = {nullptr, nullptr};
+    yolo2_hip_det *hdets[2] = {nullptr, nullptr};
+    int *hcounts[2] = {nullptr, nullptr};
 };
 
 struct F16Plan;   // yolo2_fp16.hip: the per-context launch table of the fp16 path
@@ -185,3 +202,14 @@ void y2_drv_release_i16(void);   // frees the grow-only scratch of y2_drv_conv_i
 // yolo2_fp32.hip:
 void y2_drv_conv_f32(const float *in, float *out, const float *w, const float *beta, int ifm, int ofm, int ksize, int kstride, int iw,
                      int ih, int ow, int oh, int pad, int is_nl);
+
+// yolo2_post.hip: the tail (region + boxes + NMS + record compaction) as a stage of a pipeline - caller-owned buffers, enqueue only.
+int y2_post_alloc(int device, int batch, int cap, Y2PostBufs *b);
+void y2_post_free(Y2PostBufs *b);
+size_t y2_post_geom_bytes(void);
+int y2_post_fill_geom(void *geom_host, const int *im_w, const int *im_h, int n);   // host side: correct_region_boxes' per-frame constants
+// region tensor [batch][425][13][13] int16 on `device` -> b->dets / b->counts (cap records per frame; best_only: one per detection);
+// b->geom must hold the frames' records (copied on `st` in front of this call).  Enqueues on st, returns without synchronising.
+int y2_post_enqueue_int16(int device, const int16_t *region_dev, int batch, int final_q, float thresh, float nms, int cap, int best_only,
+                          Y2PostBufs *b, hipStream_t st);
+

@@ -194,6 +194,10 @@ void y2_destroy_lanes(yolo2_hip_ctx *c)
 static void pipe_free(PipeBufs &p)
 {
     for (int k = 0; k < 2; ++k) {
+        y2_post_free(&p.post[k]);
+        if (p.hgeom[k]) (void)hipHostFree(p.hgeom[k]);
+        if (p.hdets[k]) (void)hipHostFree(p.hdets[k]);
+        if (p.hcounts[k]) (void)hipHostFree(p.hcounts[k]);
         if (p.hin[k]) (void)hipHostFree(p.hin[k]);
         if (p.hout[k]) (void)hipHostFree(p.hout[k]);
         (void)hipFree(p.dbytes[k]); (void)hipFree(p.din[k]); (void)hipFree(p.dout[k]);
@@ -447,6 +451,127 @@ extern "C" int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *c, const uint8_t *con
 }
 
 // ---------------------------------------------------------------------------- streaming host entry
+
+// Camera-to-detections entry (the whole path incl. the step after it, at the path's rate): n images as host bytes -> detection
+// records.  Per chunk of `batch` images: bytes H2D, letterbox + network on the device, the region tensor stays in HBM and
+// region + boxes + NMS + record compaction run on the SAME device and stream right behind the network; only the records
+// (32 bytes each) and the per-frame counts come back.  Upload of chunk k+1, kernels of chunk k and download of chunk k-1 overlap on
+// three HIP streams.  Replaces the loop of the reference's streaming app (linux_app/src/main.c:878-1288), which runs
+// yolo2_run_inference and the host post-processing frame by frame.
+static int pipe_ensure_post(yolo2_hip_ctx *c, int batch, int cap)
+{
+    PipeBufs &p = c->pipe;
+    if (p.post_batch >= batch && p.post_cap >= cap) return YOLO2_SUCCESS;
+    batch = std::max(batch, p.post_batch);
+    cap = std::max(cap, p.post_cap);
+    for (int k = 0; k < 2; ++k) {
+        if (p.hgeom[k]) (void)hipHostFree(p.hgeom[k]);
+        if (p.hdets[k]) (void)hipHostFree(p.hdets[k]);
+        if (p.hcounts[k]) (void)hipHostFree(p.hcounts[k]);
+        p.hgeom[k] = nullptr; p.hdets[k] = nullptr; p.hcounts[k] = nullptr;
+        p.post_batch = p.post_cap = 0;
+        const int rc = y2_post_alloc(c->device, batch, cap, &p.post[k]);
+        if (rc) return rc;
+        if (hipHostMalloc((void **)&p.hgeom[k], (size_t)batch * y2_post_geom_bytes(), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&p.hdets[k], (size_t)batch * cap * sizeof(yolo2_hip_det), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&p.hcounts[k], (size_t)batch * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(YOLO2_MMAP_ERROR, "pinned buffers for %d frames x %d detection records could not be allocated", batch, cap);
+        }
+    }
+    p.post_batch = batch; p.post_cap = cap;
+    return YOLO2_SUCCESS;
+}
+
+extern "C" int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *c, const uint8_t *const *images, const int *widths, const int *heights,
+                                            int channels, int n, int batch, float thresh, float nms, int flags, yolo2_hip_det *dets,
+                                            int cap_per_frame, int *counts, int *final_q)
+{
+    if (!c || !images || !widths || !heights || !dets || !counts) return fail(YOLO2_ERROR, "null argument");
+    if (n <= 0 || batch <= 0 || cap_per_frame <= 0) return fail(YOLO2_ERROR, "bad image count %d / batch %d / capacity %d", n, batch, cap_per_frame);
+    if (thresh < 0.f) return fail(YOLO2_ERROR, "negative threshold");
+    if (!c->weights_loaded) return fail(YOLO2_ERROR, "weights not loaded");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    batch = std::min(batch, n);
+    const int chunks = (n + batch - 1) / batch, cap = cap_per_frame, best_only = (flags & YOLO2_DETS_BEST_CLASS) ? 1 : 0;
+    auto in_chunk = [&](int k) { return std::min(batch, n - k * batch); };
+    auto padded = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t cap_bytes = 0;   // bytes of the largest chunk
+    for (int k = 0; k < chunks; ++k) {
+        size_t sum = 0;
+        for (int i = k * batch; i < k * batch + in_chunk(k); ++i) {
+            LetterboxArgs a;
+            if (!images[i]) return fail(YOLO2_ERROR, "null image %d", i);
+            const int rc = letterbox_args(widths[i], heights[i], channels, 416, 416, a);
+            if (rc) return rc;
+            sum += padded((size_t)widths[i] * heights[i] * channels);
+        }
+        cap_bytes = std::max(cap_bytes, sum);
+    }
+    if (batch != c->batch) {
+        const int rc = yolo2_hip_set_batch(c, batch);
+        if (rc) return rc;
+    }
+    int rc = pipe_ensure(c->pipe, cap_bytes, cap_bytes, batch);
+    if (rc == YOLO2_SUCCESS) rc = pipe_ensure_post(c, batch, cap);
+    if (rc) return rc;
+    PipeBufs &P = c->pipe;
+    const size_t gbytes = y2_post_geom_bytes();
+    auto cleanup = [&]() { (void)hipDeviceSynchronize(); };
+#define Y2_TRY(expr, code) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { rc = fail(code, "%s failed: %s", #expr, hipGetErrorString(e_)); cleanup(); return rc; } } while (0)
+    auto drain = [&](int k) {
+        const int b = k & 1, nf = in_chunk(k);
+        (void)hipEventSynchronize(P.e_out[b]);
+        memcpy(counts + (size_t)k * batch, P.hcounts[b], (size_t)nf * sizeof(int));
+        for (int f = 0; f < nf; ++f) {   // frame numbers are global in the caller's records
+            const int cnt = std::min(P.hcounts[b][f], cap);
+            yolo2_hip_det *dst = dets + ((size_t)k * batch + f) * cap;
+            memcpy(dst, P.hdets[b] + (size_t)f * cap, (size_t)cnt * sizeof(yolo2_hip_det));
+            for (int r = 0; r < cnt; ++r) dst[r].frame = k * batch + f;
+        }
+    };
+    int q = 0;
+    std::vector<size_t> offs((size_t)batch);
+    std::vector<int> cw((size_t)batch), chh((size_t)batch);
+    for (int k = 0; k < chunks && rc == YOLO2_SUCCESS; ++k) {
+        const int b = k & 1, nf = in_chunk(k), first = k * batch;
+        if (k >= 2) drain(k - 2);   // buffer set b is free again once chunk k-2 has left it
+        size_t off = 0;
+        for (int i = 0; i < nf; ++i) {
+            const size_t bytes = (size_t)widths[first + i] * heights[first + i] * channels;
+            memcpy(P.hin[b] + off, images[first + i], bytes);
+            offs[(size_t)i] = off;
+            off += padded(bytes);
+        }
+        for (int f = 0; f < batch; ++f) { const int i = std::min(f, nf - 1); cw[(size_t)f] = widths[first + i]; chh[(size_t)f] = heights[first + i]; }
+        if ((rc = y2_post_fill_geom(P.hgeom[b], cw.data(), chh.data(), batch))) break;
+        Y2_TRY(hipMemcpyAsync(P.dbytes[b], P.hin[b], off, hipMemcpyHostToDevice, P.s_in), YOLO2_DMA_ERROR);
+        Y2_TRY(hipMemcpyAsync(P.post[b].geom, P.hgeom[b], (size_t)batch * gbytes, hipMemcpyHostToDevice, P.s_in), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(P.e_in[b], P.s_in), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(P.s_run, P.e_in[b], 0), YOLO2_ERROR);
+        for (int f = 0; f < batch && rc == YOLO2_SUCCESS; ++f) {   // a partial last chunk repeats its last image
+            const int i = std::min(f, nf - 1);
+            rc = yolo2_hip_letterbox_u8((uint64_t)(uintptr_t)(P.dbytes[b] + offs[(size_t)i]), widths[first + i], heights[first + i], channels,
+                                        (uint64_t)(uintptr_t)(P.din[b] + (size_t)f * YOLO2_FRAME_ELEMS), 416, 416, P.s_run);
+        }
+        if (rc == YOLO2_SUCCESS) rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)P.din[b], batch, (uint64_t)(uintptr_t)P.dout[b], &q, P.s_run);
+        // the step after the path, on the device that produced the tensor, straight from HBM
+        if (rc == YOLO2_SUCCESS) rc = y2_post_enqueue_int16(c->device, P.dout[b], batch, q, thresh, nms, cap, best_only, &P.post[b], P.s_run);
+        if (rc) break;
+        Y2_TRY(hipEventRecord(P.e_run[b], P.s_run), YOLO2_ERROR);
+        Y2_TRY(hipStreamWaitEvent(P.s_out, P.e_run[b], 0), YOLO2_ERROR);
+        Y2_TRY(hipMemcpyAsync(P.hcounts[b], P.post[b].counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, P.s_out), YOLO2_DMA_ERROR);
+        Y2_TRY(hipMemcpyAsync(P.hdets[b], P.post[b].dets, (size_t)batch * cap * sizeof(yolo2_hip_det), hipMemcpyDeviceToHost, P.s_out), YOLO2_DMA_ERROR);
+        Y2_TRY(hipEventRecord(P.e_out[b], P.s_out), YOLO2_ERROR);
+    }
+    if (rc == YOLO2_SUCCESS) {
+        for (int k = std::max(0, chunks - 2); k < chunks; ++k) drain(k);
+        if (final_q) *final_q = q;
+    }
+    cleanup();
+#undef Y2_TRY
+    return rc;
+}
 
 extern "C" int yolo2_hip_run_frames_int16(yolo2_hip_ctx *c, const float *frames, int n_frames, int batch, int16_t *region,
                                           int *final_q)

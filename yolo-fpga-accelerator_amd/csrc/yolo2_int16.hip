@@ -91,6 +91,8 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
         if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
     }
     if (p.splitk) p.P = 1;
+    // 16 channels per wavefront (2-wave workgroups): 3x3, packed-accumulator forms, tiles that 128 threads stage in <= 8 items each
+    if (p.w16 && (p.splitk || p.K != 3 || (p.path != 3 && p.path != 4) || p.P > 2 || tile_items_bound(gin, 64 * p.P, halo) > 1024)) p.w16 = 0;
     const int T = p.splitk ? 64 / p.splitk * p.splitk_pp : 64 * p.P;
     ConvArgs &a = p.args;
     // (a.mb_list is owned by the caller: nullptr unless the layer is split by arithmetic form)
@@ -109,6 +111,7 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.bs_right = sb.right; a.bs_left = sb.left; a.bs_mag = sb.mag;
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
+    if (p.w16) p.lds_pad = 0;
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
     // (two channel groups per barrier for the 3x3 forms C/D - one barrier per 18 taps - was measured: -1 to -2 %)
     p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32 + 4) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
@@ -151,7 +154,7 @@ static bool plan_conv_pool(ConvPlan &p, const ActGeom &gin, const ActGeom &gpool
     const int lt = pool_tile_items_bound(gin);
     if (lt > 12 * 256) return false;
     ConvArgs &a = p.args;
-    p.splitk = 0; p.grp = 1; p.P = 4; p.lds_pad = 0;
+    p.splitk = 0; p.grp = 1; p.P = 4; p.lds_pad = 0; p.w16 = 0;
     p.pool_fused = full ? 2 : 1;
     a.lt_max = lt;
     a.nwin = gin.B * (gin.H / 2) * (gin.W / 2);
@@ -217,6 +220,16 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
             if (p.pool_fused == 2) launch_conv_pool_n<3, true>(p, in, out, out_pool, wpk, bias, st);
             else launch_conv_pool_n<3, false>(p, in, out, out_pool, wpk, bias, st);
         }
+        return;
+    }
+    if (p.w16) {
+        const int nst = (p.args.lt_max + 127) / 128;
+#define Y2_W16(PV, MODEV, NSTV) hipLaunchKernelGGL((k_conv_i16_w16<3, PV, MODEV, NSTV>), p.grid, dim3(128), p.lds_bytes, st, in, out, wpk, bias, p.args)
+#define Y2_W16_N(PV, MODEV) do { if (nst <= 2) Y2_W16(PV, MODEV, 2); else if (nst <= 4) Y2_W16(PV, MODEV, 4); else Y2_W16(PV, MODEV, 8); } while (0)
+        if (p.path == 4) { if (p.P == 2) Y2_W16_N(2, 4); else Y2_W16_N(1, 4); }
+        else { if (p.P == 2) Y2_W16_N(2, 3); else Y2_W16_N(1, 3); }
+#undef Y2_W16_N
+#undef Y2_W16
         return;
     }
     if (p.splitk) {
@@ -521,6 +534,8 @@ static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
 // over the 256 CUs; the best value depends on layer shape and batch.  Time each candidate once
 // per layer on the layer's own buffers (integer kernels: timing does not depend on the data) and
 // keep the fastest.  ~0.2 s at batch 64; disable with YOLO2_AUTOTUNE=0.
+static const bool g_no_w16 = getenv("YOLO2_NO_W16") != nullptr;   // A/B switch, latched at load time of the library
+
 static int autotune(yolo2_hip_ctx *c)
 {
     hipEvent_t e0, e1;
@@ -545,18 +560,21 @@ static int autotune(yolo2_hip_ctx *c)
         for (ConvPlan *sp : subs) {
             float best = 1e30f;
             int bestP = sp->P, bestPad = 0;
-            int bestSplit = 0, bestPP = 1;
+            int bestSplit = 0, bestPP = 1, bestW16 = 0;
             const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
-            for (int cfg = 0; cfg < 16; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14: 4 splits, 2 pixels per lane
-                const int P = cfg >= 12 ? 1 : 8 >> (cfg & 3);
+            for (int cfg = 0; cfg < 18; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14, 15: 4 splits, 2 / 4 pixels per lane; 16, 17: 16 channels per wavefront, 1 / 2 pixels per lane
+                const bool w16 = cfg >= 16;
+                const int P = w16 ? cfg - 15 : (cfg >= 12 ? 1 : 8 >> (cfg & 3));
                 const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
                 if (pad && P > 2) continue;   // the cap only matters for the small-tile, 8-waves/SIMD shapes
                 ConvPlan cand = *sp;
                 cand.lds_pad = pad;
                 cand.splitk = 0;
                 cand.splitk_pp = 1;
-                if (cfg >= 12) {
+                cand.w16 = w16 ? 1 : 0;
+                if (w16 && g_no_w16) continue;
+                if (cfg >= 12 && !w16) {
                     if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
                     cand.splitk = cfg == 13 ? 8 : 4;
                     cand.splitk_pp = cfg == 14 ? 2 : (cfg == 15 ? 4 : 1);
@@ -567,7 +585,8 @@ static int autotune(yolo2_hip_ctx *c)
                     if (probe.splitk) continue;   // forced: skip the ordinary candidates where split-K is available
                 }
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
-                if (cfg >= 12 && !cand.splitk) continue;
+                if (w16 && !cand.w16) continue;
+                if (cfg >= 12 && !w16 && !cand.splitk) continue;
                 if (cfg == 14 && cand.splitk_pp != 2) continue;
                 if (cfg == 15 && cand.splitk_pp != 4) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
@@ -583,13 +602,14 @@ static int autotune(yolo2_hip_ctx *c)
                     tmin = std::min(tmin, t);
                 }
                 if (getenv("YOLO2_VERBOSE"))
-                    fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
-                            cand.splitk, cand.grid.x, cand.grid.y, tmin * 1e3);
-                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; }
+                    fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d w16=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
+                            cand.splitk, cand.w16, cand.grid.x, cand.grid.y, tmin * 1e3);
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; bestW16 = cand.w16; }
             }
             sp->lds_pad = bestPad;
             sp->splitk = bestSplit;
             sp->splitk_pp = bestPP;
+            sp->w16 = bestW16;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
         ord++;
@@ -795,8 +815,11 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
     }
     const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
     if (fp && atoi(fp) > 0) {
+        const bool fw16 = getenv("YOLO2_FORCE_W16") != nullptr;   // ... and the 16-channels-per-wavefront kernel wherever it is legal
         for (int i = 0; i < 32; ++i) {
             if (kNet[i].type != L_CONV) continue;
+            c->plan[i].w16 = fw16;
+            for (auto &e : c->extra[i]) e.w16 = fw16;
             const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
             const Tensor &tout = c->t_out[i];
             plan_conv(c->plan[i], tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0),
@@ -835,7 +858,7 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
                 const ConvPlan &pl = c->fuse_pool[i] ? c->fplan[i] : c->plan[i];
                 if (grid_x) *grid_x = pl.grid.x;
                 if (grid_y) *grid_y = pl.grid.y;
-                if (block) *block = 256;
+                if (block) *block = pl.w16 ? 128 : 256;   // 128 = k_conv_i16_w16 (16 output channels per wavefront)
                 if (lds_bytes) *lds_bytes = pl.lds_bytes;
                 if (ppl) *ppl = pl.splitk ? 0 : pl.P;
                 return YOLO2_SUCCESS;

@@ -585,3 +585,27 @@ extern "C" int yolo2_hip_multi_run_images_u8_host(yolo2_hip_multi *m, const uint
     if (rc == YOLO2_SUCCESS && final_q) *final_q = q[0];
     return rc;
 }
+
+extern "C" int yolo2_hip_multi_run_images_u8_dets(yolo2_hip_multi *m, const uint8_t *const *images, const int *widths, const int *heights,
+                                                  int channels, int n, int batch_per_device, float thresh, float nms, int flags,
+                                                  yolo2_hip_det *dets, int cap_per_frame, int *counts, int *final_q)
+{
+    if (!m || !images || !widths || !heights || !dets || !counts) return mfail(YOLO2_ERROR, "null argument");
+    if (n <= 0 || batch_per_device <= 0 || cap_per_frame <= 0) return mfail(YOLO2_ERROR, "bad image count / batch / capacity");
+    std::vector<int> q(m->ctx.size(), 0);
+    const int rc = multi_run(m, n, [&](yolo2_hip_ctx *c, int lo, int hi) {
+        int qq = 0;
+        // shard [lo, hi): its own device runs the network AND the tail; records are renumbered to global frame indices below
+        const int r = yolo2_hip_run_images_u8_dets(c, images + lo, widths + lo, heights + lo, channels, hi - lo, std::min(batch_per_device, hi - lo),
+                                                   thresh, nms, flags, dets + (size_t)lo * cap_per_frame, cap_per_frame, counts + lo, &qq);
+        if (r == YOLO2_SUCCESS)
+            for (int f = lo; f < hi; ++f)
+                for (int k = 0, cnt = std::min(counts[f], cap_per_frame); k < cnt; ++k) dets[(size_t)f * cap_per_frame + k].frame = f;
+        for (size_t i = 0; i < m->ctx.size(); ++i)
+            if (m->ctx[i] == c) q[i] = qq;
+        return r;
+    });
+    if (rc == YOLO2_SUCCESS && final_q) *final_q = q[0];
+    return rc;
+}
+

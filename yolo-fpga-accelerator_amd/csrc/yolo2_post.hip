@@ -33,10 +33,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "../../include/yolo2_hip.h"
+#include "y2_internal.hpp"
 
 extern "C" int yolo2_hip_set_error(int code, const char *msg);
-extern "C" int yolo2_hip_ctx_device(yolo2_hip_ctx *ctx);
 
 namespace {
 
@@ -64,7 +63,6 @@ struct Luts {          // per (device, Q): device pointers to three 65536-entry 
     float *expf_ = nullptr;      // [v + 32768] = expf(v * 2^-Q)
 };
 std::mutex g_mu;        // guards the table cache
-std::mutex g_call_mu;   // one post-processing call at a time per process: the scratch buffers are per device, not per call
 std::map<std::pair<int, int>, Luts> g_luts;
 
 struct FrameGeom {     // per-frame letterbox correction constants (correct_region_boxes), computed on the host
@@ -287,9 +285,11 @@ struct DetRec {   // == yolo2_hip_det
     float prob, x, y, w, h;
 };
 
-// records for prob > 0 in the reference's print order (dets in array order, classes inner), at most cap per frame
+// records for prob > 0 in the reference's print order (dets in array order, classes inner), at most cap per frame.
+// best_only: ONE record per detection that has any prob > 0 - its best class, the first one among equals (what the reference's
+// streaming app prints, linux_app/src/main.c:1040-1052); then a frame never has more than 845 records.
 __global__ __launch_bounds__(256) void k_compact_dets(const float *__restrict__ rows, const int *__restrict__ totals, int cap,
-                                                      DetRec *__restrict__ out, int *__restrict__ counts)
+                                                      DetRec *__restrict__ out, int *__restrict__ counts, int best_only)
 {
     __shared__ int cnt[kDets + 3];
     __shared__ int wsum[4];
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_compact_dets(const float *__restrict__ 
         int c = 0;
         if (p < total)
             for (int j = 0; j < kClasses; ++j) c += frows[(size_t)p * kEntries + 5 + j] > 0.f;
-        cnt[p] = c;
+        cnt[p] = best_only ? (c > 0) : c;
     }
     __syncthreads();
     int v[4], s = 0;
@@ -320,6 +320,13 @@ __global__ __launch_bounds__(256) void k_compact_dets(const float *__restrict__ 
         if (p < total && v[k]) {
             const float *r = frows + (size_t)p * kEntries;
             int at = run;
+            if (best_only) {
+                int bj = 0;
+                float bp = 0.f;
+                for (int j = 0; j < kClasses; ++j)
+                    if (r[5 + j] > bp) { bp = r[5 + j]; bj = j; }
+                if (at < cap) out[(size_t)f * cap + at] = DetRec{f, p, bj, bp, r[0], r[1], r[2], r[3]};
+            } else
             for (int j = 0; j < kClasses; ++j)
                 if (r[5 + j] > 0.f) {
                     if (at < cap) out[(size_t)f * cap + at] = DetRec{f, p, j, r[5 + j], r[0], r[1], r[2], r[3]};
@@ -377,29 +384,20 @@ FrameGeom frame_geom(int w, int h)
     return g;
 }
 
-// Scratch per call size, kept per device and grown on demand.
-struct Scratch {
-    size_t cap_frames = 0, cap_dets = 0;
-    float *rows = nullptr, *rows2 = nullptr;
-    int *totals = nullptr, *counts = nullptr;
-    FrameGeom *geom = nullptr;
-    DetRec *dets = nullptr;
-};
-std::map<int, Scratch> g_scratch;
-
-int ensure_scratch(int device, int batch, int cap, Scratch **out)
+// Device buffers of one post-processing call in flight.  The public synchronous entries keep one set per device (g_scratch, one call
+// at a time per device); the streaming entries (yolo2_hip.hip) own one set per pipeline stage (y2_post_alloc / y2_post_free).
+int alloc_bufs(Y2PostBufs &s, int batch, int cap)
 {
-    Scratch &s = g_scratch[device];
-    if (s.cap_frames < (size_t)batch) {
+    if (s.cap_frames < batch) {
         for (void *p : {(void *)s.rows, (void *)s.rows2, (void *)s.totals, (void *)s.counts, (void *)s.geom}) (void)hipFree(p);
-        s = Scratch{0, s.cap_dets, nullptr, nullptr, nullptr, nullptr, nullptr, s.dets};
+        s.rows = s.rows2 = nullptr; s.totals = s.counts = nullptr; s.geom = nullptr; s.cap_frames = 0;
         const size_t rb = (size_t)batch * kDets * kEntries * sizeof(float);
         HIPP_TRY(hipMalloc((void **)&s.rows, rb), YOLO2_MMAP_ERROR);
         HIPP_TRY(hipMalloc((void **)&s.rows2, rb), YOLO2_MMAP_ERROR);
         HIPP_TRY(hipMalloc((void **)&s.totals, (size_t)batch * sizeof(int)), YOLO2_MMAP_ERROR);
         HIPP_TRY(hipMalloc((void **)&s.counts, (size_t)batch * sizeof(int)), YOLO2_MMAP_ERROR);
         HIPP_TRY(hipMalloc((void **)&s.geom, (size_t)batch * sizeof(FrameGeom)), YOLO2_MMAP_ERROR);
-        s.cap_frames = (size_t)batch;
+        s.cap_frames = batch;
     }
     const size_t need = (size_t)batch * (size_t)cap;
     if (s.cap_dets < need) {
@@ -408,8 +406,26 @@ int ensure_scratch(int device, int batch, int cap, Scratch **out)
         HIPP_TRY(hipMalloc((void **)&s.dets, need * sizeof(DetRec)), YOLO2_MMAP_ERROR);
         s.cap_dets = need;
     }
-    *out = &s;
     return YOLO2_SUCCESS;
+}
+std::map<int, Y2PostBufs> g_scratch;
+std::map<int, std::mutex> g_dev_mu;   // one synchronous call at a time PER DEVICE (the shared scratch set); devices do not wait for each other
+
+// The three kernels, enqueued on `st`; nothing is synchronised.  geom_dev: `batch` FrameGeom records already on the device (or on
+// their way: copied on `st` in front of this call).  proc_dev optional.
+template <typename T>
+void enqueue(const T *region, const Luts &l, int final_q, int batch, float thresh, float nms, int cap, int best_only, Y2PostBufs &s,
+             float *proc_dev, hipStream_t st, float **final_rows)
+{
+    In<T> in{region, l.logistic, l.softexp, l.expf_, std::ldexp(1.0f, -final_q)};
+    hipLaunchKernelGGL((k_region_rows<T>), dim3(batch), dim3(256), 0, st, in, batch, (const FrameGeom *)s.geom, thresh, s.rows, s.totals, proc_dev);
+    float *fr = s.rows;
+    if (nms > 0.f) {
+        hipLaunchKernelGGL(k_nms_rows, dim3(batch), dim3(256), 0, st, s.rows, s.totals, nms, s.rows2);
+        fr = s.rows2;
+    }
+    if (cap > 0) hipLaunchKernelGGL(k_compact_dets, dim3(batch), dim3(256), 0, st, fr, s.totals, cap, (DetRec *)s.dets, s.counts, best_only);
+    if (final_rows) *final_rows = fr;
 }
 
 template <typename T>
@@ -438,15 +454,24 @@ int postprocess(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, int final_q,
                          attr.device, device);
     }
     hipStream_t st = (hipStream_t)stream;
-    std::lock_guard<std::mutex> lk(g_call_mu);
+    std::mutex *dev_mu;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        dev_mu = &g_dev_mu[device];
+    }
+    std::lock_guard<std::mutex> lk(*dev_mu);
     Luts l;
     if (std::is_same<T, short>::value) {
         const int rc = get_luts(device, final_q, l);
         if (rc) return rc;
     }
-    Scratch *s = nullptr;
     const int cap = dets ? cap_per_frame : 1;
-    int rc = ensure_scratch(device, batch, cap, &s);
+    Y2PostBufs *s;
+    {
+        std::lock_guard<std::mutex> lk2(g_mu);
+        s = &g_scratch[device];
+    }
+    int rc = alloc_bufs(*s, batch, cap);
     if (rc) return rc;
     std::vector<FrameGeom> g((size_t)batch);
     for (int f = 0; f < batch; ++f) {
@@ -457,14 +482,8 @@ int postprocess(yolo2_hip_ctx *ctx, uint64_t region_dev, int batch, int final_q,
     HIPP_TRY(hipStreamSynchronize(st), YOLO2_DMA_ERROR);      // g is a local
     float *proc_dev = nullptr;
     if (proc_host) HIPP_TRY(hipMalloc((void **)&proc_dev, (size_t)batch * YOLO2_REGION_ELEMS * sizeof(float)), YOLO2_MMAP_ERROR);
-    In<T> in{(const T *)(uintptr_t)region_dev, l.logistic, l.softexp, l.expf_, std::ldexp(1.0f, -final_q)};
-    hipLaunchKernelGGL((k_region_rows<T>), dim3(batch), dim3(256), 0, st, in, batch, s->geom, thresh, s->rows, s->totals, proc_dev);
-    float *final_rows = s->rows;
-    if (nms > 0.f) {
-        hipLaunchKernelGGL(k_nms_rows, dim3(batch), dim3(256), 0, st, s->rows, s->totals, nms, s->rows2);
-        final_rows = s->rows2;
-    }
-    if (dets) hipLaunchKernelGGL(k_compact_dets, dim3(batch), dim3(256), 0, st, final_rows, s->totals, cap, s->dets, s->counts);
+    float *final_rows = nullptr;
+    enqueue<T>((const T *)(uintptr_t)region_dev, l, final_q, batch, thresh, nms, dets ? cap : 0, 0, *s, proc_dev, st, &final_rows);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && dets) e = hipMemcpyAsync(counts, s->counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, st);
     if (e == hipSuccess && dets) e = hipMemcpyAsync(dets, s->dets, (size_t)batch * cap * sizeof(DetRec), hipMemcpyDeviceToHost, st);
@@ -492,3 +511,43 @@ extern "C" int yolo2_hip_postprocess_f32(yolo2_hip_ctx *ctx, uint64_t region_dev
 {
     return postprocess<float>(ctx, region_dev, batch, 0, im_w, im_h, thresh, nms, dets, cap_per_frame, counts, rows, totals, proc, stream);
 }
+
+// ---------------------------------------------------------------------------- internal: the tail as part of a pipeline (yolo2_hip.hip)
+
+int y2_post_alloc(int device, int batch, int cap, Y2PostBufs *b)
+{
+    HIPP_TRY(hipSetDevice(device), YOLO2_INIT_ERROR);
+    return alloc_bufs(*b, batch, cap);
+}
+
+void y2_post_free(Y2PostBufs *b)
+{
+    for (void *p : {(void *)b->rows, (void *)b->rows2, (void *)b->totals, (void *)b->counts, (void *)b->geom, (void *)b->dets}) (void)hipFree(p);
+    *b = Y2PostBufs();
+}
+
+size_t y2_post_geom_bytes(void) { return sizeof(FrameGeom); }
+
+int y2_post_fill_geom(void *geom_host, const int *im_w, const int *im_h, int n)
+{
+    FrameGeom *g = static_cast<FrameGeom *>(geom_host);
+    for (int f = 0; f < n; ++f) {
+        if (im_w[f] <= 0 || im_h[f] <= 0) return pfail(YOLO2_ERROR, "bad image size for frame %d", f);
+        g[f] = frame_geom(im_w[f], im_h[f]);
+    }
+    return YOLO2_SUCCESS;
+}
+
+int y2_post_enqueue_int16(int device, const int16_t *region_dev, int batch, int final_q, float thresh, float nms, int cap, int best_only,
+                          Y2PostBufs *b, hipStream_t st)
+{
+    if (final_q < -15 || final_q > 30) return pfail(YOLO2_ERROR, "final Q %d out of range", final_q);
+    if (batch > b->cap_frames || (size_t)batch * (size_t)cap > b->cap_dets) return pfail(YOLO2_ERROR, "post-processing buffers too small for %d frames x %d records", batch, cap);
+    Luts l;
+    const int rc = get_luts(device, final_q, l);
+    if (rc) return rc;
+    enqueue<short>(region_dev, l, final_q, batch, thresh, nms, cap, best_only, *b, nullptr, st, nullptr);
+    HIPP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+

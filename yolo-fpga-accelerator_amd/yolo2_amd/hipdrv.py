@@ -42,6 +42,7 @@ EXPORTS = [
     "yolo2_hip_rccl_init_rank", "yolo2_hip_rccl_finalize", "yolo2_hip_load_weights_int16_bcast", "yolo2_hip_load_weights_fp32_bcast",
     "yolo2_hip_rccl_info", "yolo2_hip_multi_rccl_info", "yolo2_hip_ctx_device", "yolo2_hip_alloc_on",
     "yolo2_hip_fp16_layer_kernel", "yolo2_hip_f16_store_check",
+    "yolo2_hip_run_images_u8_dets", "yolo2_hip_multi_run_images_u8_dets",
 ]
 
 
@@ -145,6 +146,8 @@ def lib():
     L.yolo2_hip_rccl_finalize.argtypes = [vp]
     L.yolo2_hip_load_weights_int16_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, i32, vp, i32, vp, i32, i32]
     L.yolo2_hip_load_weights_fp32_bcast.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i32]
+    L.yolo2_hip_run_images_u8_dets.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, i32, vp, i32, vp, C.POINTER(i32)]
+    L.yolo2_hip_multi_run_images_u8_dets.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, i32, vp, i32, vp, C.POINTER(i32)]
     L.yolo2_hip_rccl_info.argtypes = [vp, vp]
     L.yolo2_hip_multi_rccl_info.argtypes = [vp, vp]
     L.yolo2_hip_ctx_device.argtypes = [vp]
@@ -462,6 +465,27 @@ def postprocess(ctx, region_ptr: int, batch: int, im_w, im_h, thresh: float, nms
                                              vp(rows), vp(totals), vp(proc), C.c_void_p(stream))
     check(rc, "yolo2_hip_postprocess")
     return {"dets": [dets[f, :min(int(counts[f]), cap)] for f in range(batch)], "counts": counts, "rows": rows, "totals": totals, "proc": proc}
+
+
+DETS_BEST_CLASS = 1
+
+
+def run_images_dets(handle, images, batch: int, thresh: float, nms: float, cap: int = 845, best_class: bool = True, multi: bool = False):
+    """yolo2_hip_run_images_u8_dets / yolo2_hip_multi_run_images_u8_dets: host images (uint8 [h][w][3]) -> per-frame detection
+    records; letterbox, network and the tail run on the device(s), the region tensor never leaves HBM."""
+    imgs = [np.ascontiguousarray(im, dtype=np.uint8) for im in images]
+    n = len(imgs)
+    ch = 1 if imgs[0].ndim == 2 else imgs[0].shape[2]
+    ptrs = (C.c_void_p * n)(*[im.ctypes.data for im in imgs])
+    ws = (C.c_int * n)(*[im.shape[1] for im in imgs])
+    hs = (C.c_int * n)(*[im.shape[0] for im in imgs])
+    dets = np.zeros((n, cap), dtype=DET_DTYPE)
+    counts = np.zeros(n, dtype=np.int32)
+    q = C.c_int(0)
+    fn = lib().yolo2_hip_multi_run_images_u8_dets if multi else lib().yolo2_hip_run_images_u8_dets
+    check(fn(handle, ptrs, ws, hs, ch, n, batch, thresh, nms, DETS_BEST_CLASS if best_class else 0, dets.ctypes.data_as(C.c_void_p), cap,
+             counts.ctypes.data_as(C.c_void_p), C.byref(q)), "yolo2_hip_run_images_u8_dets")
+    return {"dets": [dets[f, :min(int(counts[f]), cap)] for f in range(n)], "counts": counts, "final_q": q.value}
 
 
 # ------------------------------------------------------------------ more than one GPU
