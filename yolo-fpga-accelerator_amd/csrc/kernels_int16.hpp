@@ -170,7 +170,8 @@ __device__ __forceinline__ long step64(long acc, int2 x, int2 w, const ConvArgs 
 #endif
 #ifndef Y2_I16_ABL
 #define Y2_I16_ABL 0   // diagnostic builds only (tools/build_variant.sh): 1 = every group re-reads group 0's weight slice (scalar-cache hits:
-                       // what the per-tap scalar loads cost), 2 = no input staging inside the loop, 4 = no workgroup barrier inside the loop.
+                       // what the per-tap scalar loads cost), 2 = no input staging inside the loop, 4 = no workgroup barrier inside the loop,
+                       // 8 = weights loaded once per workgroup (no scalar loads in the loop), 16 = one input item per lane (no LDS reads in the loop).
                        // Results are wrong with any of them; only the timing is of interest.
 #endif
 template <int KS, int P, int MODE, int NST, int GRP = 1>
@@ -276,6 +277,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
     __syncthreads();
 
     int chain = 0;
+#if (Y2_I16_ABL & 8)
+    int2 abl_w[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) abl_w[m] = wq[m];
+#endif
+#if (Y2_I16_ABL & 16)
+    int2 abl_x = lds[tid & 63];
+#endif
     const int niter = a.CGin / GRP;   // the host only selects GRP > 1 when it divides CGin
     for (int cg = 0; cg < niter; ++cg) {
         // branch-free: the last group re-fetches its own tile instead of testing `cg + 1 < niter`
@@ -298,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 #pragma unroll
         for (int gb = 0; gb < GRP / PFG; ++gb) {
         int2 xv[PREX ? KT * PFG : 1][P];
-        if (PREX) {
+        if (PREX && !(Y2_I16_ABL & 16)) {
 #pragma unroll
             for (int tt = 0; tt < KT * PFG; ++tt)
 #pragma unroll
@@ -308,13 +317,22 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
         for (int tt = 0; tt < KT * PFG; ++tt) {
             const int tap = gb * KT * PFG + tt;
             int2 w[8];
+#if (Y2_I16_ABL & 8)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { w[m] = abl_w[m]; asm volatile("" : "+s"(w[m].x), "+s"(w[m].y)); }
+#else
 #pragma unroll
             for (int m = 0; m < 8; ++m) w[m] = wq[tap * 32 + m];  // wave-uniform: scalar loads
+#endif
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 int2 x;
+#if (Y2_I16_ABL & 16)
+                x = abl_x; asm volatile("" : "+v"(x.x), "+v"(x.y));
+#else
                 if (PREX) x = xv[tt][p];
                 else x = *xaddr(tap, p);
+#endif
                 // Form A's dot products do not depend on the accumulators, so hipcc would compute
                 // all 72x8 of a group up front (hundreds of live registers, SGPR spills).  An empty
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
