@@ -382,7 +382,9 @@ def sub_latency_b1(ctx, frames, region, dev, n=30):
     """configs[1] under the driver's clock: one frame per call, one host sync per frame (device-resident in and out)."""
     stream = torch.cuda.current_stream(dev)
     ctx.set_batch(1)
-    split = [l.idx for l in net.CONVS if ctx.conv_launch_info(l.ord)["pixels_per_lane"] == 0]
+    ppl = {l.idx: ctx.conv_launch_info(l.ord)["pixels_per_lane"] for l in net.CONVS}
+    split = [i for i, v in ppl.items() if v == 0]
+    ks = {i: -v for i, v in ppl.items() if v < 0}
     for _ in range(3):
         ctx.run_batch_ptr(frames.data_ptr(), 1, region.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize(dev)
@@ -396,9 +398,11 @@ def sub_latency_b1(ctx, frames, region, dev, n=30):
     return {"metric": "YOLOv2 INT16 416x416 single-frame latency", "value": ts[len(ts) // 2], "unit": "ms/frame", "higher_is_better": False,
             "min_ms": ts[0], "p90_ms": ts[int(0.9 * (len(ts) - 1))], "frames": n, "frames_per_s": 1e3 / ts[len(ts) // 2],
             "config": {"workload": "YOLOv2 INT16 416x416 batch=1, one host sync per frame, frame and region tensor device-resident"},
-            "split_k_layers": split,
-            "note": "split_k_layers run k_conv_i16_splitk (the saturating chain split four or eight ways, clamp-affine maps combined "
-                    "with wavefront shuffles); chosen per layer by set_batch's timing"}
+            "split_k_layers": split, "k_split_over_workgroups": ks,
+            "note": "split_k_layers run k_conv_i16_splitk (the saturating chain split four or eight ways over the lanes of a wavefront, "
+                    "clamp-affine maps combined with wavefront shuffles); k_split_over_workgroups {layer: splits} run k_conv_i16_ks "
+                    "(the chain split over S workgroups with wave-uniform weights, triples applied in order by k_ks_finalize); "
+                    "per layer as the plan table / set_batch's timing says"}
 
 
 def main():

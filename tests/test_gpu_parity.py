@@ -290,6 +290,57 @@ def test_fullnet_sixteen_channels_per_wavefront(qset, path, P, monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("P", [1, 2, 4])
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_form_d_one_register_per_channel(qset, P, monkeypatch):
+    """Form D's variant without v_perm (k_conv_i16 MODE 5, round 3: one accumulator register per channel, value in the high half,
+    increment = high half of the dot result added with v_pk_add_i16 clamp) forced on every form D launch: same weights, same
+    legality, the same bits - against the reference fixture (5 frames: tiles straddle frames) and the oracle."""
+    monkeypatch.setenv("YOLO2_FORCE_P", str(P))
+    monkeypatch.setenv("YOLO2_FORCE_HIACC", "1")
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 9, 3), synth.frames(fseed, 1)])
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    assert ctx.layer_paths().count(4) >= 15
+    region, _ = ctx.run_batch_host(frames)
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    assert np.array_equal(region[0], want) and np.array_equal(region[4], want)
+    orclib.oracle().orc_set_threads(16)
+    ri, _, _ = orclib.forward_i16(model, frames[3])
+    assert np.array_equal(region[3].reshape(-1), ri)
+    ctx.close()
+
+
+@pytest.mark.parametrize("S", [2, 4, 8, 16])
+@pytest.mark.parametrize("batch", [1, 3])
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_ksplit_across_workgroups(qset, batch, S, monkeypatch):
+    """k_conv_i16_ks + k_ks_finalize (round 3, single-frame latency): the saturating chain of every output split over S WORKGROUPS,
+    each leaving the clamp-affine triple of its sub-chain (packed int16: a wraps, l and h saturate), applied in order to the shifted
+    bias by the finalize kernel.  Forced on every 3x3 form D layer where S divides the channel groups; bit-exact against the
+    reference fixture / the oracle and equal to the unsplit result."""
+    monkeypatch.setenv("YOLO2_FORCE_P", "1")
+    monkeypatch.setenv("YOLO2_FORCE_KS", str(S))
+    model = synth.SynthModel(seed=int(FULL["meta/model_seed"]), **_qsets()[qset])
+    fseed = int(FULL["meta/frame_seed"])
+    frames = np.concatenate([synth.frames(fseed, 1), synth.frames(fseed + 3, 2)])[:batch]
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    ctx.set_batch(batch)
+    ks = [ctx.conv_launch_info(l.ord)["pixels_per_lane"] for l in net.CONVS]
+    assert sum(k == -S for k in ks) >= (12 if S <= 8 else 11), ks      # every 3x3 layer with >= 2 S channel groups (layer 2 has 8)
+    region, _ = ctx.run_batch_host(frames)
+    want = FULL[f"i16/{qset}/region_raw_i16"].reshape(425, 13, 13)
+    assert np.array_equal(region[0], want)
+    if batch > 1:
+        orclib.oracle().orc_set_threads(16)
+        ri, _, _ = orclib.forward_i16(model, frames[2])
+        assert np.array_equal(region[2].reshape(-1), ri)
+    ctx.close()
+
+
 @pytest.mark.parametrize("path", [None, "0"])
 @pytest.mark.parametrize("qset", ["std", "varq"])
 def test_fullnet_split_k(qset, path, monkeypatch):

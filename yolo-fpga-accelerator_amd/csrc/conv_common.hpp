@@ -35,6 +35,10 @@ struct ConvArgs {
     long pool_base;            // item offset of its channel group 0, incl. lead
     // division by H*W, W (and, fused pool, by (H/2)*(W/2), W/2) as multiply-high + shift: layout.hpp fast_div, set by set_conv_div
     unsigned mHW, sHW, mW, sW, mOHW, sOHW, mOW, sOW;
+    // K-split across workgroups (k_conv_i16_ks, small batches): grid.y = blocks x ks_S; split z runs channel groups [z ks_Q, (z + 1) ks_Q)
+    // and leaves the clamp-affine triples of its sub-chains in ks_trip[z][channel item][pixel][2 pairs][a, l, h]
+    int ks_S, ks_Q, ks_mb;     // splits, groups per split, blocks in this launch (grid.y / ks_S)
+    int *ks_trip;
 };
 
 inline void set_conv_div(ConvArgs &a)

@@ -121,6 +121,48 @@ __device__ __forceinline__ void stepD8(int &acc01, int &acc23, int &acc45, int &
         : "v"(sel));
 }
 
+// Form D without the v_perm ("MODE 5"): every channel keeps its accumulator in the HIGH half of a register of its own and takes
+// its increment straight from the high half of its dot result with one v_pk_add_i16 clamp (the low halves add up the dot results'
+// fraction bits with saturation - never read).  Same instruction count as form D (16 dots + 8 packed adds instead of 16 + 4 + 4)
+// and twice the accumulator registers, but no v_perm and no perm -> add dependency: tools/ubench_step.hip measures 12.75 against
+// 13.62 issue cycles per step for the bare sequences at eight wavefronts per SIMD (profiles/r03_ubench_step.txt).  Same weights,
+// same legality and the same bits as form D; the host picks per layer by timing / the plan table.
+__device__ __forceinline__ void stepE8(int (&acc)[8], const int2 x, const int2 *w, const int r)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
+        "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
+        "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
+        "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
+        "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
+        "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
+        "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
+        "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
+        "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %25, %7"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "s"(w[0].x), "s"(w[1].x), "s"(w[2].x), "s"(w[3].x), "s"(w[4].x), "s"(w[5].x), "s"(w[6].x), "s"(w[7].x),
+          "s"(w[0].y), "s"(w[1].y), "s"(w[2].y), "s"(w[3].y), "s"(w[4].y), "s"(w[5].y), "s"(w[6].y), "s"(w[7].y),
+          "v"(x.x), "v"(x.y), "v"(r));
+    // (DOT result -> non-DOT reader needs 3 instructions in between: t0's last dot is 8 instructions back, t7's 7 by the time it is read)
+    asm("v_pk_add_i16 %0, %0, %8 clamp\n\t"
+        "v_pk_add_i16 %1, %1, %9 clamp\n\t"
+        "v_pk_add_i16 %2, %2, %10 clamp\n\t"
+        "v_pk_add_i16 %3, %3, %11 clamp\n\t"
+        "v_pk_add_i16 %4, %4, %12 clamp\n\t"
+        "v_pk_add_i16 %5, %5, %13 clamp\n\t"
+        "v_pk_add_i16 %6, %6, %14 clamp\n\t"
+        "v_pk_add_i16 %7, %7, %15 clamp"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+        : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(t4), "v"(t5), "v"(t6), "v"(t7));
+}
+
 // Form B (4 instructions per step, needs the tighter bound checked by the host): keep the
 // accumulator pre-shifted, Bv = acc*2^s + round.  Then
 //     Bv' = clamp( ((Bv + p) & ~(2^s-1)) | round )        with bounds  {-32768,32767}*2^s + round
@@ -160,6 +202,7 @@ __device__ __forceinline__ long step64(long acc, int2 x, int2 w, const ConvArgs 
 // MODE 2: 64-bit path, any Q / any weights (reference arithmetic verbatim).
 // MODE 3: 32-bit form C (packed int16 accumulators, saturating packed add), 3.5 instructions per step.
 // MODE 4: form D = form C on weights pre-scaled by 2^(16-s): shift-free, 3 instructions per step.
+// MODE 5: form D with one accumulator register per channel (value in the high half) and no v_perm (stepE8).
 // NST: staging registers per thread, 256*NST >= LDS tile items.
 // GRP (1x1 convs only): channel groups staged and consumed per barrier.  A 1x1 conv has one tap per
 //      group, i.e. only 8*P steps between barriers; with GRP = 8 the loop body looks like a 3x3
@@ -234,6 +277,12 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
 #pragma unroll
             for (int p = 0; p < P; ++p) acc[p][m] = b0;
         }
+        if (MODE == 5) {   // value in the high half (the host proved |bias0| <= 32767)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) acc[p][m] = (acc_t)((int)acc[p][m] << 16);
+        }
         if (MODE == 3 || MODE == 4) {  // pack channel pairs (2j, 2j+1) into acc[p][j]; the host proved |bias0| <= 32767
             int pk[4];
 #pragma unroll
@@ -299,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
         const char *tile = lds_b + (cg & 1) * buf_items * 8;
         // Small tiles (P <= 2): fetch the whole group's input values up front, so the LDS latency of a
         // tap is not exposed when few wavefronts are resident (the tail of a launch at modest batch).
-        constexpr bool PREX = (MODE == 3 || MODE == 4) && P <= PREX_MAX_P;
+        constexpr bool PREX = (MODE == 3 || MODE == 4 || MODE == 5) && P <= PREX_MAX_P;
         // LDS address of "tap" t of pixel p: group t / KT of this barrier interval, spatial tap t % KT
         auto xaddr = [&](int t, int p) -> const int2 * {
             return reinterpret_cast<const int2 *>(tile + (t / KT) * (a.lt_max * 8) + rowaddr[p][(t % KT) / KS] + ((t % KT) % KS) * 8);
@@ -338,7 +387,14 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
                 // asm ties this pixel's x to the previous pixel's last accumulator: same order as
                 // form B gets naturally from accumulating into acc.  No instruction is emitted.
                 if (MODE == 0) asm volatile("" : "+v"(x.x) : "v"(chain));
-                if (MODE == 4) {
+                if (MODE == 5) {
+                    int ae[8];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) ae[m] = (int)acc[p][m];
+                    stepE8(ae, x, w, r_vgpr);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) acc[p][m] = (acc_t)ae[m];
+                } else if (MODE == 4) {
                     int a01 = (int)acc[p][0], a23 = (int)acc[p][1], a45 = (int)acc[p][2], a67 = (int)acc[p][3];
                     stepD8(a01, a23, a45, a67, x, w, r_vgpr, 0x07060302);
                     acc[p][0] = (acc_t)a01; acc[p][1] = (acc_t)a23; acc[p][2] = (acc_t)a45; acc[p][3] = (acc_t)a67;
@@ -394,6 +450,7 @@ __global__ __launch_bounds__(256, 2) void k_conv_i16(const int2 *__restrict__ in
             for (int t = 0; t < 4; ++t) {
                 int e = (int)acc[p][g * 4 + t];
                 if (MODE == 1) e >>= s;  // back from the pre-shifted domain
+                if (MODE == 5) e >>= 16;
                 if (MODE == 3 || MODE == 4) {   // unpack channel g*4+t from its pair register
                     const int pr = (int)acc[p][(g * 4 + t) >> 1];
                     e = (t & 1) ? (pr >> 16) : (int)(short)(pr & 0xffff);
@@ -943,6 +1000,189 @@ __global__ __launch_bounds__(256) void k_conv_i16_splitk(const int2 *__restrict_
             if (valid[p] && cgo < a.CGout) out[a.out_base + (long)cgo * a.out_cg_stride + fo[p]] = o;
         }
     }
+}
+
+// ------------------------------------------------------------------ K-split across WORKGROUPS, wave-uniform weights (single frames)
+//
+// k_conv_i16_splitk above splits the saturating chain across the LANES of a wavefront, which makes the weights lane-dependent
+// (four weight slices staged through LDS per iteration) and leaves a 13x13 layer of one frame with 192 workgroups of one
+// wavefront per SIMD: 159 us for the 1024 -> 1024 layer where the chip's issue rate allows ~40.  Here the split is across
+// workgroups: a workgroup is exactly k_conv_i16's (64 pixels x 32 channels, input tile in LDS, weights by scalar loads straight
+// into SGPR operands) but walks only channel groups [z Q, (z + 1) Q) and carries, instead of the accumulator, the clamp-affine
+// triple (a, l, h) of that sub-chain per output channel - packed int16 pairs exactly like the lane-split kernel's PACK form
+// (a wraps, l and h saturate; form D layers only: every increment is the high half of a dot result).  The S triples of an output
+// are applied in order to the shifted bias by k_ks_finalize (x -> clamp(x + a, l, h), S times), which also does the leaky and the
+// store.  S x more workgroups at the same wavefront efficiency: 13x13 at one frame becomes 3 tiles x 32 blocks x 8 splits = 768
+// workgroups.  Bit-exact by the same argument as the lane-split kernel (tests: test_fullnet_ksplit_*).
+__device__ __forceinline__ void stepT8(int (&pa)[4], int (&pl)[4], int (&ph)[4], const int2 x, const int2 *w, const int r, const int sel)
+{
+    int t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_dot2_i32_i16 %0, %8, %24, %26\n\t"
+        "v_dot2_i32_i16 %1, %9, %24, %26\n\t"
+        "v_dot2_i32_i16 %2, %10, %24, %26\n\t"
+        "v_dot2_i32_i16 %3, %11, %24, %26\n\t"
+        "v_dot2_i32_i16 %4, %12, %24, %26\n\t"
+        "v_dot2_i32_i16 %5, %13, %24, %26\n\t"
+        "v_dot2_i32_i16 %6, %14, %24, %26\n\t"
+        "v_dot2_i32_i16 %7, %15, %24, %26\n\t"
+        "v_dot2_i32_i16 %0, %16, %25, %0\n\t"
+        "v_dot2_i32_i16 %1, %17, %25, %1\n\t"
+        "v_dot2_i32_i16 %2, %18, %25, %2\n\t"
+        "v_dot2_i32_i16 %3, %19, %25, %3\n\t"
+        "v_dot2_i32_i16 %4, %20, %25, %4\n\t"
+        "v_dot2_i32_i16 %5, %21, %25, %5\n\t"
+        "v_dot2_i32_i16 %6, %22, %25, %6\n\t"
+        "v_dot2_i32_i16 %7, %23, %25, %7"
+        : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "s"(w[0].x), "s"(w[1].x), "s"(w[2].x), "s"(w[3].x), "s"(w[4].x), "s"(w[5].x), "s"(w[6].x), "s"(w[7].x),
+          "s"(w[0].y), "s"(w[1].y), "s"(w[2].y), "s"(w[3].y), "s"(w[4].y), "s"(w[5].y), "s"(w[6].y), "s"(w[7].y),
+          "v"(x.x), "v"(x.y), "v"(r));
+    // increments of the four channel pairs (high halves), then a += t (wrapping), l = sat16(l + t), h = sat16(h + t)
+    asm("v_perm_b32 %12, %13, %12, %20\n\t"
+        "v_perm_b32 %14, %15, %14, %20\n\t"
+        "v_perm_b32 %16, %17, %16, %20\n\t"
+        "v_perm_b32 %18, %19, %18, %20\n\t"
+        "v_pk_add_u16 %0, %0, %12\n\t"
+        "v_pk_add_i16 %4, %4, %12 clamp\n\t"
+        "v_pk_add_i16 %8, %8, %12 clamp\n\t"
+        "v_pk_add_u16 %1, %1, %14\n\t"
+        "v_pk_add_i16 %5, %5, %14 clamp\n\t"
+        "v_pk_add_i16 %9, %9, %14 clamp\n\t"
+        "v_pk_add_u16 %2, %2, %16\n\t"
+        "v_pk_add_i16 %6, %6, %16 clamp\n\t"
+        "v_pk_add_i16 %10, %10, %16 clamp\n\t"
+        "v_pk_add_u16 %3, %3, %18\n\t"
+        "v_pk_add_i16 %7, %7, %18 clamp\n\t"
+        "v_pk_add_i16 %11, %11, %18 clamp"
+        : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pl[0]), "+v"(pl[1]), "+v"(pl[2]), "+v"(pl[3]), "+v"(ph[0]), "+v"(ph[1]),
+          "+v"(ph[2]), "+v"(ph[3]), "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3), "+v"(t4), "+v"(t5), "+v"(t6), "+v"(t7)
+        : "v"(sel));
+}
+
+template <int KS, int NST>
+__global__ __launch_bounds__(256, 2) void k_conv_i16_ks(const int2 *__restrict__ in, const int2 *__restrict__ wpk, const ConvArgs a)
+{
+    extern __shared__ int2 lds[];
+    constexpr int KT = KS * KS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tile = blockIdx.x, yb = blockIdx.y;
+    if (a.xcd_remap) xcd_partition(a.xcd_remap - 1, tile, yb);
+    const int z = yb / a.ks_mb, ybm = yb - z * a.ks_mb;        // split, block slot
+    const int mb = a.mb_list ? a.mb_list[ybm] : ybm;
+    const int q0 = tile * 64, qlast = min(q0 + 64, a.npix) - 1;
+    const int halo = (KS == 3) ? a.Wp + 1 : 0;
+    const int fmin = flat_of(a, q0), fmax = flat_of(a, qlast);
+    const int tile_start = fmin - halo;
+    const int Lt = min(fmax - fmin + 1 + 2 * halo, a.lt_max);
+    const int q = q0 + lane;
+    const bool valid = q <= qlast;
+    const int lo = flat_of(a, min(q, qlast)) - tile_start;
+    int rowaddr[KS];
+#pragma unroll
+    for (int i = 0; i < KS; ++i) rowaddr[i] = (KS == 3) ? (lo + (i - 1) * a.Wp - 1) * 8 : lo * 8;
+
+    int pa[4], pl[4], ph[4];     // the sub-chain's map per channel pair (2j, 2j + 1): identity on int16
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { pa[j] = 0; pl[j] = (int)0x80008000u; ph[j] = 0x7fff7fff; }
+    int r_vgpr = a.round;
+    asm volatile("" : "+v"(r_vgpr));
+    const char *lds_b = reinterpret_cast<const char *>(lds);
+    const int g0 = z * a.ks_Q;
+    const int2 *src = in + kLead + tile_start + (long)g0 * a.in_cg_stride;
+    const int2 *wq = wpk + (((long)mb * a.CGin + g0) * KT * 32 + wave * 8);
+
+    int2 stage[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) stage[k] = src[i];
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+        const int i = tid + k * 256;
+        if (i < Lt) lds[i] = stage[k];
+    }
+    __syncthreads();
+    for (int cg = 0; cg < a.ks_Q; ++cg) {
+        src += (cg + 1 < a.ks_Q) ? a.in_cg_stride : 0;
+#pragma unroll
+        for (int k = 0; k < NST; ++k) {
+            const int i = tid + k * 256;
+            if (i < Lt) stage[k] = src[i];
+        }
+        const char *tl = lds_b + (cg & 1) * a.lt_max * 8;
+        int2 xv[KT];
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt) xv[tt] = *reinterpret_cast<const int2 *>(tl + rowaddr[tt / KS] + (tt % KS) * 8);
+#pragma unroll
+        for (int tt = 0; tt < KT; ++tt) {
+            int2 w[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) w[m] = wq[tt * 32 + m];   // wave-uniform: scalar loads
+            stepT8(pa, pl, ph, xv[tt], w, r_vgpr, 0x07060302);
+        }
+        {
+            int2 *nxt = lds + ((cg + 1) & 1) * a.lt_max;
+#pragma unroll
+            for (int k = 0; k < NST; ++k) {
+                const int i = tid + k * 256;
+                if (i < Lt) nxt[i] = stage[k];
+            }
+        }
+        wq += KT * 32;
+        __syncthreads();
+    }
+    // triples out: [split][channel item][pixel][pair 0: a l h, pair 1: a l h]
+    if (valid) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int cgo = mb * 8 + wave * 2 + g;
+            if (cgo >= a.CGout) continue;
+            int *dst = a.ks_trip + (((long)z * a.CGout + cgo) * a.npix + q) * 6;
+            *reinterpret_cast<int2 *>(dst) = make_int2(pa[2 * g], pl[2 * g]);
+            *reinterpret_cast<int2 *>(dst + 2) = make_int2(ph[2 * g], pa[2 * g + 1]);
+            *reinterpret_cast<int2 *>(dst + 4) = make_int2(pl[2 * g + 1], ph[2 * g + 1]);
+        }
+    }
+}
+
+// applies the S sub-chain maps of every output in order to its shifted bias, then leaky + store (one thread per pixel and item)
+__global__ __launch_bounds__(256) void k_ks_finalize(const int *__restrict__ trip, int2 *__restrict__ out, const short *__restrict__ bias,
+                                                      const ConvArgs a)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.npix * a.CGout) return;
+    const int cgo = t / a.npix, q = t - cgo * a.npix;
+    int e[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int b = bias[cgo * 4 + k];       // (bias_pk is padded to whole blocks of 32)
+        e[k] = a.bs_right ? ((b + (a.bs_mag > 0 ? (1 << (a.bs_mag - 1)) : 0)) >> a.bs_mag) : (a.bs_left ? (b << a.bs_mag) : b);
+    }
+    for (int z = 0; z < a.ks_S; ++z) {
+        const int *src = trip + (((long)z * a.CGout + cgo) * a.npix + q) * 6;
+        const int2 v0 = *reinterpret_cast<const int2 *>(src), v1 = *reinterpret_cast<const int2 *>(src + 2), v2 = *reinterpret_cast<const int2 *>(src + 4);
+        const int pa[2] = {v0.x, v1.y}, pl[2] = {v0.y, v2.x}, ph[2] = {v1.x, v2.y};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = k >> 1, hi = k & 1;
+            const int a16 = hi ? (pa[j] >> 16) : (int)(short)(pa[j] & 0xffff);
+            const int l = hi ? (pl[j] >> 16) : (int)(short)(pl[j] & 0xffff);
+            const int h = hi ? (ph[j] >> 16) : (int)(short)(ph[j] & 0xffff);
+            // the true sum of the increments: f(-32768) = l and f(32767) = h confine it to [h - 32767, l + 32768] (see k_conv_i16_splitk)
+            const int lo = h - 32767;
+            const int at = lo + ((a16 - lo) & 0xffff);
+            e[k] = min(max(e[k] + at, l), h);
+        }
+    }
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = a.leaky ? leaky_i16(e[k]) : e[k];
+    int2 o;
+    o.x = (v[0] & 0xffff) | (v[1] << 16);
+    o.y = (v[2] & 0xffff) | (v[3] << 16);
+    out[a.out_base + (long)cgo * a.out_cg_stride + flat_of(a, q)] = o;
 }
 
 // ------------------------------------------------------------------ small kernels

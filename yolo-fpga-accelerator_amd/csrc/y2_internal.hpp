@@ -65,6 +65,8 @@ struct ConvPlan {
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
     int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
     int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
+    int ks = 0;                // single frames: K-split across workgroups (k_conv_i16_ks + k_ks_finalize); 0 or the number of splits
+    int hiacc = 0;             // form D launches only: 1 = the kernel keeps one accumulator register per channel (no v_perm: MODE 5)
     int w16 = 0;               // 1: k_conv_i16_w16 - two wavefronts of 16 output channels each per workgroup instead of four of 8
     int grp = 1;               // 1x1 convs: channel groups per barrier (8 when it divides CGin and fits LDS staging)
     int pool_fused = 0;        // conv + leaky + 2x2 pool in one kernel (k_conv_i16_pool): 1 = pooled tensor only, 2 = + full tensor
@@ -128,6 +130,8 @@ struct yolo2_hip_ctx {
     std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV], maxabs_mb[YOLO2_N_CONV];
     std::vector<signed char> wscale_mb[YOLO2_N_CONV];   // log2 of the factor each block's packed weights currently carry (form D)
     int *mb_lists = nullptr;           // device: block index lists of all split layers
+    int *ks_trip = nullptr;            // device scratch of the K-split-across-workgroups kernel (triples of every split), grown on demand
+    size_t ks_trip_bytes = 0;
     // Lanes: a batch is run as part-batches on internal streams (forked from / joined to the
     // caller's stream with events).  Every layer is then several concurrent launches, and the idle tail of
     // one (a layer is only a few workgroup-generations long at batch 64) is filled by the others.

@@ -148,6 +148,9 @@ extern "C" int yolo2_hip_ctx_device(yolo2_hip_ctx *c) { return c ? c->device : -
 
 void y2_free_activations(yolo2_hip_ctx *c)
 {
+    if (c->ks_trip) (void)hipFree(c->ks_trip);
+    c->ks_trip = nullptr;
+    c->ks_trip_bytes = 0;
     if (c->t_in.d) (void)hipFree(c->t_in.d);
     c->t_in.d = nullptr;
     if (c->t_cat.d) (void)hipFree(c->t_cat.d);

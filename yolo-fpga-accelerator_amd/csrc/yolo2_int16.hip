@@ -21,6 +21,8 @@
 
 using namespace y2;
 
+constexpr int kKsMaxBatch = 4;     // k_conv_i16_ks is a latency kernel: contexts of more frames never plan it
+
 // ---------------------------------------------------------------------------- launch helpers
 
 struct ShiftSpec {
@@ -95,6 +97,10 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
         //  pixel tile, and halving the tile to 8 pixels measured 2x slower)
         if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
     }
+    if (p.ks) {   // K-split across workgroups: form D 3x3 launches, whole groups per split, at least two groups each
+        if (p.splitk || p.mb_count || p.path != 4 || p.K != 3 || gin.CG % p.ks != 0 || gin.CG / p.ks < 2 || tile_items_bound(gin, 64, halo) > kMaxTileItems) p.ks = 0;
+        else { p.P = 1; p.w16 = 0; p.hiacc = 0; }
+    }
     if (p.splitk) p.P = 1;
     // 16 channels per wavefront (2-wave workgroups): 3x3, packed-accumulator forms, tiles that 128 threads stage in <= 8 items each
     if (p.w16 && (p.splitk || p.K != 3 || (p.path != 3 && p.path != 4) || p.P > 2 || tile_items_bound(gin, 64 * p.P, halo) > 1024)) p.w16 = 0;
@@ -117,10 +123,13 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     a.leaky = p.leaky;
     a.lt_max = tile_items_bound(gin, T, halo);
     if (p.w16) p.lds_pad = 0;
+    if (p.hiacc && (p.path != 4 || p.splitk || p.w16 || p.P > 4)) p.hiacc = 0;   // (8 pixels per lane x 8 accumulators does not leave room for the rest)
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !getenv("YOLO2_NO_GRP")) ? 8 : 1;
     // (two channel groups per barrier for the 3x3 forms C/D - one barrier per 18 taps - was measured: -1 to -2 %)
     p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32 + 4) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
+    a.ks_S = p.ks; a.ks_Q = p.ks ? gin.CG / p.ks : 0; a.ks_mb = (int)p.grid.y;
+    if (p.ks) { p.grid.y *= p.ks; p.lds_pad = 0; }
     // XCD grid over (tiles, blocks): bytes crossing the fabric = input x Xm + weights x Xt x G, where
     // G > 1 only if the blocks one XCD owns do not keep their weights in its 4 MiB L2 (then every
     // generation of co-resident tiles fetches them again).  See xcd_partition in kernels_int16.hpp.
@@ -215,7 +224,7 @@ static void launch_conv_p(const ConvPlan &p, const int2 *in, int2 *out, const in
 }
 
 static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st,
-                        int2 *out_pool = nullptr)
+                        int2 *out_pool = nullptr, int *ks_trip = nullptr)
 {
     if (p.pool_fused) {   // out_pool: the pooled tensor (the layer after this conv)
         if (p.path == 4) {
@@ -225,6 +234,16 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
             if (p.pool_fused == 2) launch_conv_pool_n<3, true>(p, in, out, out_pool, wpk, bias, st);
             else launch_conv_pool_n<3, false>(p, in, out, out_pool, wpk, bias, st);
         }
+        return;
+    }
+    if (p.ks && ks_trip) {   // (the finalize covers the WHOLE layer, which is why plan_conv refuses ks for layers split by arithmetic form)
+        ConvArgs a = p.args;
+        a.ks_trip = ks_trip;     // the context's scratch (sized by ensure_ks_scratch)
+        const int nst = (a.lt_max + 255) / 256;
+        if (nst <= 2) hipLaunchKernelGGL((k_conv_i16_ks<3, 2>), p.grid, dim3(256), p.lds_bytes, st, in, wpk, a);
+        else if (nst <= 4) hipLaunchKernelGGL((k_conv_i16_ks<3, 4>), p.grid, dim3(256), p.lds_bytes, st, in, wpk, a);
+        else hipLaunchKernelGGL((k_conv_i16_ks<3, 8>), p.grid, dim3(256), p.lds_bytes, st, in, wpk, a);
+        hipLaunchKernelGGL(k_ks_finalize, dim3(blocks_for((long)a.npix * a.CGout, 256)), dim3(256), 0, st, (const int *)ks_trip, out, bias, a);
         return;
     }
     if (p.w16) {
@@ -260,12 +279,14 @@ static void launch_conv(const ConvPlan &p, const int2 *in, int2 *out, const int2
     }
     if (p.K == 3) {
         if (p.path == 2) launch_conv_p<3, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4 && p.hiacc) launch_conv_p<3, 5>(p, in, out, wpk, bias, st);
         else if (p.path == 4) launch_conv_p<3, 4>(p, in, out, wpk, bias, st);
         else if (p.path == 3) launch_conv_p<3, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<3, 1>(p, in, out, wpk, bias, st);
         else launch_conv_p<3, 0>(p, in, out, wpk, bias, st);
     } else {
         if (p.path == 2) launch_conv_p<1, 2>(p, in, out, wpk, bias, st);
+        else if (p.path == 4 && p.hiacc) launch_conv_p<1, 5>(p, in, out, wpk, bias, st);
         else if (p.path == 4) launch_conv_p<1, 4>(p, in, out, wpk, bias, st);
         else if (p.path == 3) launch_conv_p<1, 3>(p, in, out, wpk, bias, st);
         else if (p.path == 1) launch_conv_p<1, 1>(p, in, out, wpk, bias, st);
@@ -539,6 +560,8 @@ static int alloc_tensor(Tensor &t, int C, int H, int W, int B)
 // over the 256 CUs; the best value depends on layer shape and batch.  Time each candidate once
 // per layer on the layer's own buffers (integer kernels: timing does not depend on the data) and
 // keep the fastest.  ~0.2 s at batch 64; disable with YOLO2_AUTOTUNE=0.
+static const bool g_no_hiacc = getenv("YOLO2_NO_HIACC") != nullptr;
+static const bool g_no_ks = getenv("YOLO2_NO_KS") != nullptr;
 static const bool g_no_w16 = getenv("YOLO2_NO_W16") != nullptr;   // A/B switch, latched at load time of the library
 
 static int autotune(yolo2_hip_ctx *c)
@@ -565,10 +588,15 @@ static int autotune(yolo2_hip_ctx *c)
         for (ConvPlan *sp : subs) {
             float best = 1e30f;
             int bestP = sp->P, bestPad = 0;
-            int bestSplit = 0, bestPP = 1, bestW16 = 0;
+            int bestSplit = 0, bestPP = 1, bestW16 = 0, bestHi = 0, bestKs = 0;
             const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
-            for (int cfg = 0; cfg < 18; ++cfg) {   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14, 15: 4 splits, 2 / 4 pixels per lane; 16, 17: 16 channels per wavefront, 1 / 2 pixels per lane
+            for (int cfgx = 0; cfgx < 18 + 12 + 4; ++cfgx) {   // 18..29: the tile shapes 0..11 again with one accumulator register per channel (form D launches); 30..33: K-split across workgroups, 2 / 4 / 8 / 16 splits
+                const int ks = cfgx >= 30 ? 2 << (cfgx - 30) : 0;
+                const int cfg = ks ? 3 : (cfgx >= 18 ? cfgx - 18 : cfgx);     // (ks: P = 1, no cap)
+                const bool hiacc = cfgx >= 18 && !ks;
+                if (hiacc && (sp->path != 4 || g_no_hiacc)) continue;
+                if (ks && (c->batch > kKsMaxBatch || !c->ks_trip || g_no_ks || (fs && atoi(fs) == 1))) continue;   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14, 15: 4 splits, 2 / 4 pixels per lane; 16, 17: 16 channels per wavefront, 1 / 2 pixels per lane
                 const bool w16 = cfg >= 16;
                 const int P = w16 ? cfg - 15 : (cfg >= 12 ? 1 : 8 >> (cfg & 3));
                 const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
@@ -578,6 +606,8 @@ static int autotune(yolo2_hip_ctx *c)
                 cand.splitk = 0;
                 cand.splitk_pp = 1;
                 cand.w16 = w16 ? 1 : 0;
+                cand.hiacc = hiacc ? 1 : 0;
+                cand.ks = ks;
                 if (w16 && g_no_w16) continue;
                 if (cfg >= 12 && !w16) {
                     if (!sp->splitk_ok || !c->extra[i].empty() || (fs && atoi(fs) == 0)) continue;
@@ -591,6 +621,8 @@ static int autotune(yolo2_hip_ctx *c)
                 }
                 plan_conv(cand, tin.g, tout.g.cg_stride, out_base, CGout, P);
                 if (w16 && !cand.w16) continue;
+                if (hiacc && !cand.hiacc) continue;
+                if (ks && cand.ks != ks) continue;
                 if (cfg >= 12 && !w16 && !cand.splitk) continue;
                 if (cfg == 14 && cand.splitk_pp != 2) continue;
                 if (cfg == 15 && cand.splitk_pp != 4) continue;
@@ -599,7 +631,7 @@ static int autotune(yolo2_hip_ctx *c)
                 for (int rep = 0; rep < 2; ++rep) {
                     (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
                     (void)hipEventRecord(e0, nullptr);
-                    launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr);
+                    launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr, nullptr, c->ks_trip);
                     (void)hipEventRecord(e1, nullptr);
                     HIP_TRY(hipEventSynchronize(e1), YOLO2_ERROR);
                     float t = 0;
@@ -607,14 +639,16 @@ static int autotune(yolo2_hip_ctx *c)
                     tmin = std::min(tmin, t);
                 }
                 if (getenv("YOLO2_VERBOSE"))
-                    fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d w16=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
-                            cand.splitk, cand.w16, cand.grid.x, cand.grid.y, tmin * 1e3);
-                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; bestW16 = cand.w16; }
+                    fprintf(stderr, "[yolo2_hip] tune L%d path %d: P=%d pad=%d splitk=%d w16=%d hiacc=%d ks=%d grid=(%u,%u) %.1f us\n", i, cand.path, P, pad,
+                            cand.splitk, cand.w16, cand.hiacc, cand.ks, cand.grid.x, cand.grid.y, tmin * 1e3);
+                if (tmin < best) { best = tmin; bestP = P; bestPad = pad; bestSplit = cand.splitk; bestPP = cand.splitk_pp; bestW16 = cand.w16; bestHi = cand.hiacc; bestKs = cand.ks; }
             }
             sp->lds_pad = bestPad;
             sp->splitk = bestSplit;
             sp->splitk_pp = bestPP;
             sp->w16 = bestW16;
+            sp->hiacc = bestHi;
+            sp->ks = bestKs;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, CGout, bestP);
         }
         ord++;
@@ -631,7 +665,7 @@ static int setup_pool_fusion(yolo2_hip_ctx *c, bool timed, bool default_on);
 
 // ---------------------------------------------------------------------------- the plan table (deterministic launch plans)
 //
-// One line per (frames in the context, conv layer, sub-launch):  B L S path P pad splitk pp w16 fuse
+// One line per (frames in the context, conv layer, sub-launch):  B L S path P pad splitk pp w16 fuse hiacc ks
 // (S = 0 the layer's main launch, 1.. its extra launches for blocks of another arithmetic form; `fuse` = conv + pool in one
 // kernel, stated on S = 0).  A line only applies if `path` equals the form the loader proved for that launch - a table measured
 // on other weights or Q values falls back to timing instead of forcing a shape onto another kernel.  The file shipped in
@@ -639,7 +673,7 @@ static int setup_pool_fusion(yolo2_hip_ctx *c, bool timed, bool default_on);
 // the batches the bench, the tests' full-size cases and the CLI defaults use.  YOLO2_PLAN_FILE=<file> replaces it, YOLO2_AUTOTUNE=1
 // ignores it (always time), YOLO2_AUTOTUNE=0 neither reads it for unknown batches nor times (static heuristic).
 namespace {
-struct PlanLine { int path, P, pad, splitk, pp, w16, fuse; };
+struct PlanLine { int path, P, pad, splitk, pp, w16, fuse, hiacc, ks; };
 struct PlanTable {
     std::mutex mu;
     bool loaded = false;
@@ -670,7 +704,9 @@ void load_plan_table()
     while (fgets(line, sizeof(line), f)) {
         int B, L, S;
         PlanLine pl;
-        if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d", &B, &L, &S, &pl.path, &pl.P, &pl.pad, &pl.splitk, &pl.pp, &pl.w16, &pl.fuse) != 10) continue;
+        pl.hiacc = pl.ks = 0;
+        if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d %d", &B, &L, &S, &pl.path, &pl.P, &pl.pad, &pl.splitk, &pl.pp, &pl.w16, &pl.fuse,
+                                     &pl.hiacc, &pl.ks) < 10) continue;
         if (!g_plans.lines.count({B, {L, S}})) g_plans.per_batch[B]++;
         g_plans.lines[{B, {L, S}}] = pl;       // a later line for the same key wins (appended re-measurements)
     }
@@ -711,7 +747,7 @@ static int apply_plan_table(yolo2_hip_ctx *c, bool *known)
         for (size_t s = 0; s < nsub; ++s, ++k) {
             ConvPlan *sp = todo[k].first;
             const PlanLine &pl = todo[k].second;
-            sp->lds_pad = pl.pad; sp->splitk = pl.splitk; sp->splitk_pp = pl.pp; sp->w16 = pl.w16;
+            sp->lds_pad = pl.pad; sp->splitk = pl.splitk; sp->splitk_pp = pl.pp; sp->w16 = pl.w16; sp->hiacc = pl.hiacc; sp->ks = pl.ks;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, (kNet[i].n + 3) / 4, pl.P);
             if (sp->P != pl.P && !sp->splitk) return fail(YOLO2_ERROR, "plan table: layer %d cannot run %d pixels per lane at batch %d", i, pl.P, c->batch);
         }
@@ -737,8 +773,8 @@ static void record_plan(yolo2_hip_ctx *c)
         std::vector<const ConvPlan *> subs{&c->plan[i]};
         for (auto &e : c->extra[i]) subs.push_back(&e);
         for (size_t s = 0; s < subs.size(); ++s)
-            fprintf(f, "%d %d %zu %d %d %d %d %d %d %d\n", c->batch, i, s, subs[s]->path, subs[s]->P, subs[s]->lds_pad, subs[s]->splitk, subs[s]->splitk_pp,
-                    subs[s]->w16, s == 0 && c->fuse_pool[i] ? 1 : 0);
+            fprintf(f, "%d %d %zu %d %d %d %d %d %d %d %d %d\n", c->batch, i, s, subs[s]->path, subs[s]->P, subs[s]->lds_pad, subs[s]->splitk, subs[s]->splitk_pp,
+                    subs[s]->w16, s == 0 && c->fuse_pool[i] ? 1 : 0, subs[s]->hiacc, subs[s]->ks);
     }
     fclose(f);
 }
@@ -799,7 +835,7 @@ static int setup_pool_fusion(yolo2_hip_ctx *c, bool timed, bool default_on)
                 (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
                 (void)hipEventRecord(e0, nullptr);
                 if (variant == 0) {
-                    launch_conv(c->plan[i], tin.d, tout.d, wp, bp, nullptr);
+                    launch_conv(c->plan[i], tin.d, tout.d, wp, bp, nullptr, nullptr, c->ks_trip);
                     for (const auto &e : c->extra[i]) launch_conv(e, tin.d, tout.d, wp, bp, nullptr);
                     launch_maxpool(tout, tpool, c->batch, nullptr);
                 } else {
@@ -920,6 +956,12 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
                 if ((rc = alloc_tensor(c->t_out[i], l.c, l.h / 2, l.w / 2, batch))) return rc;
             }
         }
+        // scratch of the K-split-across-workgroups kernel (single frames, <= 4 per call): up to 16 splits of the largest eligible layer
+        if (batch <= kKsMaxBatch) {
+            const size_t need = (size_t)16 * 24 * std::max((size_t)128 * 676, (size_t)256 * 169) * (size_t)batch;
+            HIP_TRY(hipMalloc((void **)&c->ks_trip, need), YOLO2_MMAP_ERROR);
+            c->ks_trip_bytes = need;
+        }
         c->t_out[24] = c->t_cat;  // conv-24 output and the reorg output live in the concat tensor
         c->t_out[27] = c->t_cat;  // (yolo2_model.cpp:97-104 does the same by arena placement)
         c->batch = batch;
@@ -935,11 +977,15 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
     }
     const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
     if (fp && atoi(fp) > 0) {
-        const bool fw16 = getenv("YOLO2_FORCE_W16") != nullptr;   // ... and the 16-channels-per-wavefront kernel wherever it is legal
+        const bool fw16 = getenv("YOLO2_FORCE_W16") != nullptr;
+        const bool fhi = getenv("YOLO2_FORCE_HIACC") != nullptr;
+        const int fks = getenv("YOLO2_FORCE_KS") ? atoi(getenv("YOLO2_FORCE_KS")) : 0;   // ... and the K-split-across-workgroups kernel (batch <= 4)  // ... and form D's one-register-per-channel variant   // ... and the 16-channels-per-wavefront kernel wherever it is legal
         for (int i = 0; i < 32; ++i) {
             if (kNet[i].type != L_CONV) continue;
             c->plan[i].w16 = fw16;
-            for (auto &e : c->extra[i]) e.w16 = fw16;
+            c->plan[i].hiacc = fhi;
+            c->plan[i].ks = (fks > 0 && batch <= kKsMaxBatch) ? fks : 0;
+            for (auto &e : c->extra[i]) { e.w16 = fw16; e.hiacc = fhi; }
             const Tensor &tin = i == 0 ? c->t_in : (i == 26 ? c->t_out[16] : (i == 29 ? c->t_cat : c->t_out[i - 1]));
             const Tensor &tout = c->t_out[i];
             plan_conv(c->plan[i], tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0),
@@ -991,7 +1037,7 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
                 if (grid_y) *grid_y = pl.grid.y;
                 if (block) *block = pl.w16 ? 128 : 256;   // 128 = k_conv_i16_w16 (16 output channels per wavefront)
                 if (lds_bytes) *lds_bytes = pl.lds_bytes;
-                if (ppl) *ppl = pl.splitk ? 0 : pl.P;
+                if (ppl) *ppl = pl.ks ? -pl.ks : (pl.splitk ? 0 : pl.P);   // 0: lane-split K kernel; -S: K split over S workgroups
                 return YOLO2_SUCCESS;
             }
             o++;
@@ -1056,7 +1102,7 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
                 launch_conv(c->fplan[i], tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
                 for (const auto &e : c->fextra[i]) launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st, c->t_out[i + 1].d);
             } else {
-                launch_conv(c->plan[i], tin->d, c->t_out[i].d, wp, bp, st);
+                launch_conv(c->plan[i], tin->d, c->t_out[i].d, wp, bp, st, nullptr, c->ks_trip);
                 for (const auto &e : c->extra[i])   // blocks of this layer that need another arithmetic form
                     launch_conv(e, tin->d, c->t_out[i].d, wp, bp, st);
             }
