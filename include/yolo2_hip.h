@@ -257,18 +257,28 @@ int yolo2_hip_layer_times_ms(yolo2_hip_ctx *ctx, float *ms32 /* [32] */);
 int yolo2_hip_num_lanes(yolo2_hip_ctx *ctx);
 /* The same for the fp16 path (two half-batch lanes from batch 64; known after the first run_batch_fp16). */
 int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *ctx);
+/* Sets that lane count (1 = no lanes; default 2, or YOLO2_F16_LANES at weight load).  Used by bench.py to time one lane's launches
+ * ALONE for the per-kernel roofline object. */
+int yolo2_hip_set_fp16_lanes(yolo2_hip_ctx *ctx, int lanes);
 
 /* 1 when conv layer `layer_idx` (0..31) runs fused with the 2x2 max pool after it (k_conv_i16_pool: the
  * full-resolution tensor is never written, except layer 16's, which also feeds the route), 0 otherwise.
  * Chosen per batch by set_batch (timed); YOLO2_NO_POOLFUSE=1 disables, YOLO2_POOLFUSE=1 forces it wherever legal. */
 int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *ctx, int layer_idx);
 
-/* Launch geometry of the conv kernel family, for the roofline report.  pixels_per_lane = 0 means
+/* Launch geometry of the conv kernel family, for the roofline report.  block = 128: k_conv_i16_w16.  pixels_per_lane = -S: the
+ * layer runs k_conv_i16_ks (chain split over S workgroups).  pixels_per_lane = 0 means
  * the layer runs the split-K kernel (64/S pixels x S K-splits per wavefront, partial clamp-affine
  * maps combined with wavefront shuffles), which set_batch picks for small batches when it times
  * faster; YOLO2_SPLITK=0 / 1 in the environment disables / forces it wherever its bounds hold. */
 int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x, int *grid_y,
                                int *block, int *lds_bytes, int *pixels_per_lane);
+
+/* The launch plan of conv layer `conv_ordinal` as text, e.g. "P=1 pad=0 w16=0 hiacc=1 ks=0 splitk=0 pp=1 grp=1 fused=0 form=4 extra=0"
+ * (pixels per lane, occupancy cap, 16-channels-per-wavefront kernel, form D without v_perm, K-split over workgroups / over lanes,
+ * 1x1 grouping, conv + pool fusion, arithmetic form, extra launches for blocks of another form).  Plans come from the committed plan
+ * table (config/plan_gfx950.txt) for the batches it knows - the same in every process - and from timing otherwise. */
+int yolo2_hip_conv_plan_string(yolo2_hip_ctx *ctx, int conv_ordinal, char *buf, int cap);
 
 /* fp32 whole network in the reference's own arithmetic (what yolov2_hls_ps does at Precision::FP32,
  * hls/models/yolov2/yolo2_model.cpp:229-449: compute() fp32 branch core_compute.cpp:121-172 in its

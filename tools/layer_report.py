@@ -30,7 +30,7 @@ for l in net.LAYERS:
         cyc = CYC.get(paths[l.ord], 16)
         ideal = st_ / 64 * cyc / 1024 / 2.4e9 * 1e3
         tot_ideal += ideal
-        print(f"L{l.idx:2d} conv{l.size} {l.c:4d}->{l.n:4d} @{l.h:3d}  P={info['pixels_per_lane']} blk={info['block']} path={paths[l.ord]} grid=({info['grid_x']},{info['grid_y']}) lds={info['lds_bytes']:6d}  {ms[l.idx]:7.3f} ms  ideal@2.4GHz {ideal:6.3f}  eff {ideal/ms[l.idx]*100:5.1f}%")
+        print(f"L{l.idx:2d} conv{l.size} {l.c:4d}->{l.n:4d} @{l.h:3d}  P={info['pixels_per_lane']} blk={info['block']} path={paths[l.ord]} [{ctx.conv_plan(l.ord)}] grid=({info['grid_x']},{info['grid_y']}) lds={info['lds_bytes']:6d}  {ms[l.idx]:7.3f} ms  ideal@2.4GHz {ideal:6.3f}  eff {ideal/ms[l.idx]*100:5.1f}%")
     elif l.type in (net.MAXPOOL, net.REORG, net.REGION):
         print(f"L{l.idx:2d} {l.type:6s}                                                       {ms[l.idx]:7.3f} ms")
 print(f"ideal conv total {tot_ideal:.3f} ms -> {B/(tot_ideal*1e-3):.0f} FPS ceiling at 2.4 GHz for these forms")

@@ -65,6 +65,7 @@ struct ConvPlan {
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
     int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
     int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
+    size_t ks_cap = 0;         // bytes of the context's triple scratch: plan_conv refuses a split whose triples would not fit
     int ks = 0;                // single frames: K-split across workgroups (k_conv_i16_ks + k_ks_finalize); 0 or the number of splits
     int hiacc = 0;             // form D launches only: 1 = the kernel keeps one accumulator register per channel (no v_perm: MODE 5)
     int w16 = 0;               // 1: k_conv_i16_w16 - two wavefronts of 16 output channels each per workgroup instead of four of 8

@@ -490,6 +490,20 @@ extern "C" const char *yolo2_hip_fp16_layer_kernel(yolo2_hip_ctx *c, int layer_i
     return "";
 }
 
+// Number of part-batch lanes the fp16 pass uses from batch 64 (default 2; 1 = none).  A measurement knob that is part of the ABI:
+// bench.py times the dominant kernel's launches ALONE (lanes = 1 at one lane's batch) for its per-kernel roofline object.
+extern "C" int yolo2_hip_set_fp16_lanes(yolo2_hip_ctx *c, int lanes)
+{
+    if (!c || !c->f16_plan) return fail(YOLO2_ERROR, "fp32 weights not loaded (yolo2_hip_load_weights_fp32)");
+    if (lanes < 1 || lanes > 8) return fail(YOLO2_ERROR, "fp16 lanes: %d out of range (1..8)", lanes);
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
+    c->f16_plan->sw.lanes = lanes;
+    for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);    // rebuilt at the next run if still wanted
+    c->f16_lanes.clear();
+    return YOLO2_SUCCESS;
+}
+
 static int make_f16_lanes(yolo2_hip_ctx *c, int want_lanes)
 {
     for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);

@@ -98,7 +98,11 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
         if ((S != 4 && !(S == 8 && p.K == 1)) || gin.CG % S != 0 || gin.CG < 4 * S || S * (lt + p.K * p.K * 32) > kMaxTileItems) p.splitk = 0;
     }
     if (p.ks) {   // K-split across workgroups: form D 3x3 launches, whole groups per split, at least two groups each
-        if (p.splitk || p.mb_count || p.path != 4 || p.K != 3 || gin.CG % p.ks != 0 || gin.CG / p.ks < 2 || tile_items_bound(gin, 64, halo) > kMaxTileItems) p.ks = 0;
+        // ... and the triples of all splits (24 bytes per output item and split) must fit the context's scratch: an overflow there
+        // is an out-of-bounds store of k_conv_i16_ks (round 3: a GPU memory fault while the scratch was sized for two layer shapes only)
+        if (p.splitk || p.mb_count || p.path != 4 || p.K != 3 || gin.CG % p.ks != 0 || gin.CG / p.ks < 2 || tile_items_bound(gin, 64, halo) > kMaxTileItems ||
+            (size_t)p.ks * (size_t)CGout * (size_t)npix * 24 > p.ks_cap)
+            p.ks = 0;
         else { p.P = 1; p.w16 = 0; p.hiacc = 0; }
     }
     if (p.splitk) p.P = 1;
@@ -958,7 +962,9 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
         }
         // scratch of the K-split-across-workgroups kernel (single frames, <= 4 per call): up to 16 splits of the largest eligible layer
         if (batch <= kKsMaxBatch) {
-            const size_t need = (size_t)16 * 24 * std::max((size_t)128 * 676, (size_t)256 * 169) * (size_t)batch;
+            // room for 16 splits of every layer at <= 52 x 52 (the largest: 64 items x 2704 pixels); larger layers have workgroups
+            // enough without a split, and plan_conv checks every plan against ks_cap
+            const size_t need = (size_t)16 * 24 * (size_t)64 * 2704 * (size_t)batch;
             HIP_TRY(hipMalloc((void **)&c->ks_trip, need), YOLO2_MMAP_ERROR);
             c->ks_trip_bytes = need;
         }
@@ -972,8 +978,10 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
         const Tensor &tout = c->t_out[i];
         const long out_base = kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0);
         const int CGout = (kNet[i].n + 3) / 4;
+        c->plan[i].ks_cap = c->ks_trip ? c->ks_trip_bytes : 0;
+        c->plan[i].ks = 0;
         plan_conv(c->plan[i], tin.g, tout.g.cg_stride, out_base, CGout);
-        for (auto &e : c->extra[i]) plan_conv(e, tin.g, tout.g.cg_stride, out_base, CGout);
+        for (auto &e : c->extra[i]) { e.ks_cap = 0; e.ks = 0; plan_conv(e, tin.g, tout.g.cg_stride, out_base, CGout); }
     }
     const char *fp = getenv("YOLO2_FORCE_P");  // test hook: one pixels-per-lane value for every layer
     if (fp && atoi(fp) > 0) {
@@ -1038,6 +1046,27 @@ extern "C" int yolo2_hip_conv_launch_info(yolo2_hip_ctx *c, int ord, int *grid_x
                 if (block) *block = pl.w16 ? 128 : 256;   // 128 = k_conv_i16_w16 (16 output channels per wavefront)
                 if (lds_bytes) *lds_bytes = pl.lds_bytes;
                 if (ppl) *ppl = pl.ks ? -pl.ks : (pl.splitk ? 0 : pl.P);   // 0: lane-split K kernel; -S: K split over S workgroups
+                return YOLO2_SUCCESS;
+            }
+            o++;
+        }
+    return fail(YOLO2_ERROR, "bad conv ordinal %d", ord);
+}
+
+// The launch plan of conv layer `ord` as text (lane 0's with lanes): "P=1 pad=0 w16=0 hiacc=1 ks=0 splitk=0 pp=1 grp=1 fused=0 form=4".
+// What bench.py discloses as the plan it ran (the plan table makes it the same in every process).
+extern "C" int yolo2_hip_conv_plan_string(yolo2_hip_ctx *c, int ord, char *buf, int cap)
+{
+    if (!c || !buf || cap <= 0) return fail(YOLO2_ERROR, "null argument");
+    if (!c->batch) return fail(YOLO2_ERROR, "set_batch first");
+    if (c->laned) return yolo2_hip_conv_plan_string(c->lanes[0], ord, buf, cap);
+    int o = 0;
+    for (int i = 0; i < 32; ++i)
+        if (kNet[i].type == L_CONV) {
+            if (o == ord) {
+                const ConvPlan &pl = c->fuse_pool[i] ? c->fplan[i] : c->plan[i];
+                snprintf(buf, (size_t)cap, "P=%d pad=%d w16=%d hiacc=%d ks=%d splitk=%d pp=%d grp=%d fused=%d form=%d extra=%zu", pl.P, pl.lds_pad, pl.w16, pl.hiacc,
+                         pl.ks, pl.splitk, pl.splitk_pp, pl.grp, pl.pool_fused, pl.path, c->extra[i].size());
                 return YOLO2_SUCCESS;
             }
             o++;
