@@ -85,8 +85,8 @@ def cpu_baseline(model, frames, gpu_regions):
         regions = [_ref_forward_one(orclib, model, frames[0])]      # ONE frame (about 6.5 s): keeps the default run short
         dt = time.perf_counter() - t0
         out = {"value": 1 / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
-               "sample": "1 frame: 23 conv + 5 maxpool layers through the reference's own YOLO2_FPGA "
-                         "(oracle/_ref, built from the reference sources), single thread, weights in memory",
+               "sample": "ONE frame, one timing sample (6.5 s; a median of three would triple the default run): 23 conv + 5 maxpool layers "
+                         "through the reference's own YOLO2_FPGA (oracle/_ref, built from the reference sources), single thread, weights in memory",
                "seconds_per_frame": dt}
     else:
         orclib.oracle().orc_set_threads(1)
@@ -219,17 +219,65 @@ print_record = None                # set by main(): writes the one JSON line to 
 MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense fp16/bf16
 
 
-def fp16_record(ctx, B, steps, dt, layer_ms, world=1):
+def fp16_solo_layer_ms(ctx, frames, region, Bl, stream, dev, steps=5):
+    """Per-layer hipEvent times of ONE lane's launches with the chip to themselves: lanes off, batch = one lane's share.  This is
+    what the per-kernel roofline object is computed from (the x lanes extrapolation of an overlapped launch's duration
+    assumed perfect co-scheduling)."""
+    ctx.set_fp16_lanes(1)
+    for _ in range(2):
+        ctx.run_batch_fp16_ptr(frames.data_ptr(), Bl, region.data_ptr(), stream.cuda_stream)
+    ctx.set_profiling(True)
+    torch.cuda.synchronize(dev)
+    for _ in range(steps):
+        ctx.run_batch_fp16_ptr(frames.data_ptr(), Bl, region.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    ms = ctx.layer_times_ms()
+    ctx.set_profiling(False)
+    return ms
+
+
+def box_iou_vs_reference(gpu_region, ref_region, obj_thresh=0.3):
+    """BASELINE.json's accuracy figure for the floating-point paths: IoU of every box the region layer decodes (all 845 cell/anchor
+    slots, no threshold, no NMS: the same slot in both tensors) between the GPU tensor and the fp32 oracle's, through the host's own
+    region + box code (libyolo2_host.so).  Also restricted to the slots whose reference objectness exceeds obj_thresh."""
+    import orclib
+    H = orclib.host()
+
+    def rows(r):
+        proc = np.zeros(425 * 169, dtype=np.float32)
+        H.y2h_region_forward(np.ascontiguousarray(r, dtype=np.float32).reshape(-1), proc)
+        out = np.zeros((845, 85), dtype=np.float32)
+        n = H.y2h_boxes_nms(proc, 640, 480, 0.0, 0.0, out, 845)
+        assert n == 845
+        return out
+    a, b = rows(gpu_region), rows(ref_region)
+    l = np.maximum(a[:, 0] - a[:, 2] / 2, b[:, 0] - b[:, 2] / 2); r = np.minimum(a[:, 0] + a[:, 2] / 2, b[:, 0] + b[:, 2] / 2)
+    tp = np.maximum(a[:, 1] - a[:, 3] / 2, b[:, 1] - b[:, 3] / 2); d = np.minimum(a[:, 1] + a[:, 3] / 2, b[:, 1] + b[:, 3] / 2)
+    inter = np.clip(r - l, 0, None) * np.clip(d - tp, 0, None)
+    iou = inter / (a[:, 2] * a[:, 3] + b[:, 2] * b[:, 3] - inter)
+    conf = b[:, 4] > obj_thresh
+    return {"boxes": 845, "box_iou_min": float(iou.min()), "box_iou_mean": float(iou.mean()),
+            "confident_boxes": int(conf.sum()), "confident_box_iou_min": float(iou[conf].min()) if conf.any() else None,
+            "max_abs_coord_err": float(np.abs(a[:, :4] - b[:, :4]).max()), "max_abs_objectness_err": float(np.abs(a[:, 4] - b[:, 4]).max()),
+            "note": f"all 845 cell/anchor slots of frame 0 (640x480 image geometry), same slot in both tensors; confident = reference objectness > {obj_thresh}"}
+
+
+def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     """Roofline objects of the fp16 MFMA path from one timed run: `dt` seconds for `steps` passes over B frames per GPU,
-    layer_ms = the library's per-layer hipEvent times of lane 0."""
-    lanes = ctx.num_lanes_fp16()     # 2: every layer is two concurrent half-batch launches; the hipEvents time lane 0's
+    layer_ms = the library's per-layer hipEvent times of lane 0 (overlapped with the other lane's launches), solo_ms = the same
+    launches with the chip to themselves (fp16_solo_layer_ms)."""
+    lanes = ctx.num_lanes_fp16() if solo_ms is None else max(1, B // max(1, solo_ms[1]))
+    if solo_ms is not None:
+        solo_ms = solo_ms[0]
     Bl = B // lanes
     conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
     halo = [l for l in net.CONVS if l.size == 3 and l.w <= 52 and l.n % 128 == 0 and l.c % 64 == 0]
-    halo_ms = float(sum(layer_ms[l.idx] for l in halo))
     halo_flops = 2.0 * Bl * sum(l.size * l.size * l.c * l.n * l.out_h * l.out_w for l in halo)
-    halo_launch_ach = halo_flops / (halo_ms * 1e-3) / 1e12      # one launch of lane 0 (shares the chip with lane 1's)
-    halo_ach = halo_launch_ach * lanes                          # chip level: `lanes` such launches run concurrently
+    halo_ms = float(sum((solo_ms if solo_ms is not None else layer_ms)[l.idx] for l in halo))
+    halo_ach = halo_flops / (halo_ms * 1e-3) / 1e12             # solo: the launch has the chip to itself, no extrapolation
+    halo_launch_ach = halo_ach
+    if solo_ms is None:                                          # (multi-GPU line: no solo pass; lane 0's overlapped launches x lanes, upper bound)
+        halo_ach = halo_launch_ach * lanes
     chip_ach = 2.0 * net.macs_per_frame() * B / (dt / steps) / 1e12
     return {
         "value": world * B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16",
@@ -240,10 +288,12 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1):
         "roofline": {"bound": "mfma", "kernel": "k_conv_f16_halo", "launches_per_step": len(halo), "layers": [l.idx for l in halo],
                      "avg_launch_ms": halo_ms / len(halo), "achieved": halo_ach, "peak": MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": None,
-                     "algorithmic_flops_per_launch": halo_flops / len(halo), "concurrent_launches": lanes,
-                     "achieved_per_launch": halo_launch_ach,
-                     "note": "achieved = concurrent_launches x (algorithmic FLOPs of one launch / its mean duration): the lanes run the "
-                             "same layer side by side and share the chip; whole_pass is measured from the wall time of the step"},
+                     "algorithmic_flops_per_launch": halo_flops / len(halo), "frames_per_launch": Bl,
+                     "timing": "solo" if solo_ms is not None else "overlapped_x_lanes",
+                     "note": ("achieved = algorithmic FLOPs of one launch / its mean duration with the chip to itself (lanes off, batch = one "
+                              "lane's share, hipEvents inside the library); the step itself runs two such launches side by side: whole_pass")
+                             if solo_ms is not None else
+                             "achieved = lanes x (FLOPs of lane 0's launch / its duration while the other lane's launches run beside it): an upper bound"},
         # chip level, independent of how the lanes' launches overlap: all conv FLOPs of the step / wall time of the step
         "whole_pass": {"scope": "all conv FLOPs of one step (both lanes) / ms_per_step", "achieved": chip_ach, "unit": "TFLOP/s",
                        "frac": chip_ach / MFMA_PEAK_TFLOPS},
@@ -294,8 +344,15 @@ def bench_fp16(args, world, rank, local_rank, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     layer_ms = ctx.layer_times_ms()
+    ctx.set_profiling(False)
+    solo = None
+    if world == 1 and ctx.num_lanes_fp16() > 1:      # the per-kernel object from launches that have the chip to themselves
+        lanes = ctx.num_lanes_fp16()
+        region0 = region[0].clone()
+        solo = (fp16_solo_layer_ms(ctx, frames, region, B // lanes, stream, dev), B // lanes)
+        region[0].copy_(region0)
     if rank == 0:
-        rec = fp16_record(ctx, B, args.steps, dt, layer_ms, world)
+        rec = fp16_record(ctx, B, args.steps, dt, layer_ms, world, solo_ms=solo)
         result = {"metric": "YOLOv2 fp16 416x416 frames/sec", "value": rec["value"], "unit": "frames/s", "n_gpus": world,
                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic"}
@@ -303,10 +360,16 @@ def bench_fp16(args, world, rank, local_rank, dev):
         if rccl is not None:
             result["rccl"], result["per_rank"] = rccl, per_rank
         if world == 1 and not args.no_cpu_baseline:
-            err, cdt = fp16_error_vs_fp32(model, frames[0].cpu().numpy(), region[0].cpu().numpy(), 1)
+            import orclib
+            orclib.oracle().orc_set_threads(1)
+            t0c = time.perf_counter()
+            ref = orclib.forward_f32(model, frames[0].cpu().numpy())
+            cdt = time.perf_counter() - t0c
+            g0 = region[0].cpu().numpy()
             result["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "frames/s", "cores": 1, "kind": "port",
                                       "sample": "1 frame through oracle/yolo2_oracle.c fp32 (bit-exact restatement of the reference's fp32 path), single thread",
-                                      "seconds_per_frame": cdt, "gpu_max_abs_err_vs_cpu": err}
+                                      "seconds_per_frame": cdt, "gpu_max_abs_err_vs_cpu": float(np.abs(g0.reshape(-1) - ref).max()),
+                                      "box_iou_vs_cpu": box_iou_vs_reference(g0, ref)}
         print_record(result)
     if dist.is_initialized():
         dist.barrier()
@@ -332,13 +395,25 @@ def sub_fp16_b256(model, dev, steps=10, warmup=3):
         ctx.run_batch_fp16_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    rec = fp16_record(ctx, B, steps, dt, ctx.layer_times_ms())
+    lane_ms = ctx.layer_times_ms()
+    ctx.set_profiling(False)
+    lanes = ctx.num_lanes_fp16()
+    region0 = region[0].cpu().numpy()
+    assert torch.equal(region[0], region[B - 8]), "fp16 path: the same frame gave different results at different batch positions"
+    solo = fp16_solo_layer_ms(ctx, frames, region, B // lanes, stream, dev)
+    rec = fp16_record(ctx, B, steps, dt, lane_ms, solo_ms=(solo, B // lanes))
+    rec["layer_ms_solo_one_lane"] = [round(float(x), 4) for x in solo]
     rec["warmup"] = warmup
     threads = min(16, len(os.sched_getaffinity(0)))
-    err, cdt = fp16_error_vs_fp32(model, base[0], region[0].cpu().numpy(), threads)
+    import orclib
+    orclib.oracle().orc_set_threads(threads)
+    t0 = time.perf_counter()
+    ref = orclib.forward_f32(model, base[0])
+    cdt = time.perf_counter() - t0
+    err = float(np.abs(region0.reshape(-1) - ref).max())
     rec["max_abs_err_vs_fp32_oracle"] = err
+    rec["box_iou_vs_fp32_oracle"] = box_iou_vs_reference(region0, ref)
     rec["error_check"] = f"frame 0 against oracle/yolo2_oracle.c fp32 on {threads} threads ({cdt:.1f} s); the region tensor spans about +-4.7"
-    assert torch.equal(region[0], region[B - 8]), "fp16 path: the same frame gave different results at different batch positions"
     ctx.close()
     return rec
 

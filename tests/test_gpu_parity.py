@@ -566,8 +566,8 @@ def test_fp16_mfma_path_vs_fp32_reference():
     """fp16 activations/weights, fp32 accumulate on the matrix cores, against the fp32 region
     tensor the compiled reference produced (tests/golden/fullnet.npz).  Tolerances: raw tensor
     |err| <= 0.03 absolute (values span +-4.7) and <= 0.4 % RMS; every box's coordinates within
-    1e-2 (relative image units; fp16 activations, the 1e-3 bound of BASELINE.json is for fp32) and
-    IoU >= 0.97 with the reference box of the same cell/anchor."""
+    1e-2 (relative image units; fp16 activations, the 1e-3 bound of BASELINE.json is for fp32) and, for ALL 845 cell/anchor
+    slots unconditionally, IoU >= 0.93 (mean >= 0.99) with the reference box of the same slot (derivation at the assert)."""
     model = synth.SynthModel(seed=1)
     frames = np.concatenate([synth.frames(7, 1), synth.frames(8, 3)])
     ctx = hipdrv.Yolo2Hip(0)
@@ -582,19 +582,23 @@ def test_fp16_mfma_path_vs_fp32_reference():
     for k in (1, 2, 3):
         ref = orclib.forward_f32(model, frames[k]).reshape(425, 13, 13)
         assert np.abs(region[k] - ref).max() <= 0.03
-    # box level
+    # box level, UNCONDITIONAL (the IoU assert used to be skipped whenever a borderline objectness flipped).  All 845
+    # cell/anchor slots are decoded without a threshold, so the same slot is compared in both tensors whatever its objectness.
+    # Bounds: a raw-tensor error of 0.03 moves a box centre by <= 0.03 / 4 of a cell (sigmoid slope 1/4) = 6e-4 of the image and
+    # scales w, h by exp(+-0.03) = +-3 %; two boxes whose sides differ by 3 % and whose centres by 0.1 % of the image overlap with
+    # IoU >= (1 - 0.03)^2 / (1 + 0.03)^2 ~ 0.89 in the worst case.  Measured on this fixture: min 0.96-0.97 depending on the kernel
+    # family's summation order (a legal variant reached 0.9686 in round 2) - asserted at 0.93, i.e. with margin on both sides.
+    _, ra = _boxes(want, 0.0)
+    _, ga = _boxes(region[0], 0.0)
+    assert len(ra) == len(ga) == 845
+    assert np.abs(ga[:, :4] - ra[:, :4]).max() <= 1e-2
+    iou = _iou(ga, ra)
+    assert iou.min() >= 0.93 and iou.mean() >= 0.99, (iou.min(), iou.mean())
+    assert np.abs(ga[:, 4] - ra[:, 4]).max() <= 8e-3            # objectness: sigmoid slope 1/4 x 0.03
+    # the thresholded view differs at most by slots whose objectness lies within that error band of the threshold
     _, rb = _boxes(want)
     _, gb = _boxes(region[0])
-    assert len(rb) > 100
-    # same cells pass the threshold except those within the error band of it
-    proc_ref, _ = _boxes(want, 0.0)
-    if len(rb) == len(gb):
-        assert np.abs(gb[:, :4] - rb[:, :4]).max() <= 1e-2
-        assert _iou(gb, rb).min() >= 0.97
-    else:   # a borderline objectness flipped: compare the unthresholded boxes instead
-        _, ra = _boxes(want, 0.0); _, ga = _boxes(region[0], 0.0)
-        assert len(ra) == len(ga) == 845
-        assert np.abs(ga[:, :4] - ra[:, :4]).max() <= 1e-2
+    assert len(rb) > 100 and abs(len(rb) - len(gb)) <= int(((ra[:, 4] > 0.3 - 8e-3) & (ra[:, 4] < 0.3 + 8e-3)).sum())
     # batch consistency: a frame alone == the same frame inside a batch (deterministic kernel)
     single = ctx.run_batch_fp16_host(frames[2:3])
     assert np.array_equal(single[0], region[2])
