@@ -36,6 +36,10 @@ for rep in range(2):      # the second run finds the files in the page cache and
     tail = [l for l in r.stdout.splitlines() if "Streaming inference completed" in l][-1]
     print(f"run {rep}: n={n} batch={batch} chunk_batches={cb} post={post}: process wall {dt:.2f} s ({n / dt:.0f} frames/s incl. start-up, weight load and planning)")
     print("   ", tail)
+    import re
+    per = [float(m.group(1)) for m in re.finditer(r"inference time: ([0-9.]+) ms", r.stdout)]
+    chunks = [per[0]] + [b for a, b in zip(per, per[1:]) if b != a]
+    print("    per-frame share of each accelerator call, ms:", " ".join(f"{x:.3f}" for x in chunks))
 nrec = sum(1 for _ in open(os.path.join(tmp, "out.jsonl")))
 assert nrec == n, (nrec, n)
 import shutil; shutil.rmtree(tmp, ignore_errors=True)

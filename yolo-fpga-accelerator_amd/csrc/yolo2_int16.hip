@@ -632,7 +632,7 @@ static int autotune(yolo2_hip_ctx *c)
                 if (cfg == 15 && cand.splitk_pp != 4) continue;
                 if (cand.P != P) continue;  // not available for this path / shape
                 float tmin = 1e30f;
-                for (int rep = 0; rep < 2; ++rep) {
+                for (int rep = 0; rep < 3; ++rep) {
                     (void)hipMemsetAsync(flush, rep, flush_bytes, nullptr);
                     (void)hipEventRecord(e0, nullptr);
                     launch_conv(cand, tin.d, tout.d, (const int2 *)(c->wpk + c->wpk_off[ord]), c->bias_pk + c->bias_off[ord], nullptr, nullptr, c->ks_trip);
