@@ -8,29 +8,27 @@ import collections, csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Dispatch_Id"]))
 steps = int(sys.argv[2])
 lanes = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-sig = [(r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in rows]
-D = None
-for d in range(8, len(sig) // max(steps, 2)):
-    if all(sig[len(sig) - (k + 1) * d: len(sig) - k * d] == sig[len(sig) - d:] for k in range(1, steps)):
-        D = d
-        break
-if D is None:
-    sys.exit("no periodic tail found")
-# one period = one lane's pass when the lanes issue identical sequences, else one step; a step = `per_step` dispatches
-per_step = D if lanes == 1 else None
-tail = rows[len(rows) - steps * D * (1 if lanes == 1 else 1):]
 qkey = "Queue_Id" if "Queue_Id" in rows[0] else "Stream_Id"
-# group the tail by queue: each queue's dispatches in order; a step of a lane = its share of the sequence
 byq = collections.defaultdict(list)
-for r in rows[len(rows) - steps * max(D, 1) * lanes:] if D * lanes * steps <= len(rows) else tail:
+for r in rows:
     byq[r[qkey]].append(r)
+# the lanes = the queues with the most dispatches; each lane's pass is the shortest period of ITS OWN dispatch sequence
 qs = sorted(byq, key=lambda q: -len(byq[q]))[:lanes]
-n_per_lane_step = min(len(byq[q]) for q in qs) // steps
-print(f"# period D = {D} dispatches; queues {qs}; {n_per_lane_step} dispatches per lane and step; times in ms relative to the step's first kernel start")
+def period(v):
+    sig = [(r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in v]
+    for d in range(8, len(sig) // max(steps, 2) + 1):
+        if all(sig[len(sig) - (k + 1) * d: len(sig) - k * d] == sig[len(sig) - d:] for k in range(1, steps)):
+            return d
+    return None
+per = {q: period(byq[q]) for q in qs}
+if any(v is None for v in per.values()):
+    sys.exit(f"no periodic tail found: {per}")
+n_per_lane_step = min(per.values())
+print(f"# queues {qs}; dispatches per lane and step {per}; times in ms relative to the step's first kernel start")
 T = lambda r, k: int(r[k])
 gaps = []
 for s in range(steps):
-    seg = {q: byq[q][len(byq[q]) - (steps - s) * n_per_lane_step: len(byq[q]) - (steps - s - 1) * n_per_lane_step] for q in qs}
+    seg = {q: byq[q][len(byq[q]) - (steps - s) * per[q]: len(byq[q]) - (steps - s - 1) * per[q]] for q in qs}
     t0 = min(T(v[0], "Start_Timestamp") for v in seg.values())
     t1 = max(T(v[-1], "End_Timestamp") for v in seg.values())
     ev = []
@@ -51,9 +49,9 @@ print("# mean over steps, ms with k kernels running concurrently:", {k: round(su
 # per position in the lane's pass: mean duration and the mean number of other kernels running meanwhile is not known; print durations
 pos = collections.defaultdict(list)
 for q in qs:
-    v = byq[q][len(byq[q]) - steps * n_per_lane_step:]
+    v = byq[q][len(byq[q]) - steps * per[q]:]
     for i, r in enumerate(v):
-        pos[i % n_per_lane_step].append((T(r, "End_Timestamp") - T(r, "Start_Timestamp"), r["Kernel_Name"].split("(")[0][-60:], r["Grid_Size_X"], r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else ""))
+        pos[i % per[q]].append((T(r, "End_Timestamp") - T(r, "Start_Timestamp"), r["Kernel_Name"].split("(")[0][-60:], r["Grid_Size_X"], r["Workgroup_Size_X"] if "Workgroup_Size_X" in r else ""))
 print("# per position in a lane's pass: mean / min / max kernel duration (us) over lanes and steps")
 for i in sorted(pos):
     d = [x[0] for x in pos[i]]

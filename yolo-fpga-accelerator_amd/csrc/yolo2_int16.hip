@@ -1008,7 +1008,10 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
     // The committed plan table first: a batch it knows is planned WITHOUT timing anything, so that every process - bench.py,
     // tools/traffic.sh, the tests, the CLI - runs the same kernels for the same batch (autotune picks differed from
     // run to run, and the committed traffic counters described another kernel set than the bench line).
-    if (!(at && at[0] == '1')) {
+    // (the A/B and test switches that steer the timed selection bypass the table: they ask for a plan the table does not hold)
+    const bool steered = getenv("YOLO2_SPLITK") || getenv("YOLO2_POOLFUSE") || getenv("YOLO2_NO_POOLFUSE") || g_no_w16 || g_no_hiacc || g_no_ks ||
+                         getenv("YOLO2_NO_GRP") || getenv("YOLO2_NO_XCD_REMAP");
+    if (!(at && at[0] == '1') && !steered) {
         bool known = false;
         const int rc = apply_plan_table(c, &known);
         if (rc) return rc;
