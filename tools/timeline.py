@@ -13,7 +13,8 @@ byq = collections.defaultdict(list)
 for r in rows:
     byq[r[qkey]].append(r)
 # the lanes = the queues with the most dispatches; each lane's pass is the shortest period of ITS OWN dispatch sequence
-qs = sorted(byq, key=lambda q: -len(byq[q]))[:lanes]
+recent = collections.Counter(r[qkey] for r in rows[-steps * 60:])     # (the null-stream queue holds set_batch's launches: not a lane)
+qs = sorted(recent, key=lambda q: -recent[q])[:lanes]
 def period(v):
     sig = [(r["Kernel_Name"], r["Grid_Size_X"], r["Grid_Size_Y"]) for r in v]
     for d in range(8, len(sig) // max(steps, 2) + 1):
