@@ -68,10 +68,10 @@ int main()
         {"4 perm + 4 pk_add only", k_tail_only, 8}, {"form D + 4 s_nop between dots and perms", k_stepD_s_nop, 28}};
     int *out;
     unsigned long long *cyc;
-    const int nblk = 256 * 4;  // 4 blocks per CU
-    hipMalloc(&out, sizeof(int) * nblk * 1024);
-    hipMalloc(&cyc, sizeof(unsigned long long) * nblk * 16);
-    std::vector<unsigned long long> h(nblk * 16);
+    const int nblk = 256 * 8;  // up to 8 blocks of 256 threads per CU
+    hipMalloc(&out, sizeof(int) * nblk * 256);
+    hipMalloc(&cyc, sizeof(unsigned long long) * nblk * 4);
+    std::vector<unsigned long long> h(nblk * 4);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -79,19 +79,20 @@ int main()
     for (auto &k : ks) {
         printf("%-50s", k.name);
         for (int wps : {1, 2, 4, 8}) {
-            const int threads = 64 * wps;  // 4 blocks/CU x wps waves = wps waves per SIMD
-            hipLaunchKernelGGL(k.f, dim3(nblk), dim3(threads), 0, 0, out, cyc, 3, 7);
+            // 256-thread blocks = one wavefront per SIMD each; wps blocks per CU = wps wavefronts per SIMD, all resident at once
+            const int threads = 256, nb = 256 * wps;
+            hipLaunchKernelGGL(k.f, dim3(nb), dim3(threads), 0, 0, out, cyc, 3, 7);
             hipDeviceSynchronize();
             hipEventRecord(e0, 0);
-            hipLaunchKernelGGL(k.f, dim3(nblk), dim3(threads), 0, 0, out, cyc, 3, 7);
+            hipLaunchKernelGGL(k.f, dim3(nb), dim3(threads), 0, 0, out, cyc, 3, 7);
             hipEventRecord(e1, 0);
             hipDeviceSynchronize();
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
-            const int nw = nblk * wps;
+            const int nw = nb * 4;
             hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * nw, hipMemcpyDeviceToHost);
             std::sort(h.begin(), h.begin() + nw);
-            const double per = (double)h[nw / 2] / ITER / wps / 8.0;                   // SIMD cycles per step (shader clock)
+            const double per = (double)h[nw / 2] / ITER / wps / 8.0;                   // SIMD cycles per step by the median wavefront's own s_memtime span
             const double wall = ms * 1e-3 * 2.4e9 / ((double)ITER * wps) / 8.0;        // the same from wall time, priced at 2.4 GHz
             printf("  %5.2f|%5.2f", per, wall);
         }
