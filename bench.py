@@ -129,7 +129,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r03_hbm_traffic.json")
 
 
 def hbm_traffic_per_launch(ks, batch):

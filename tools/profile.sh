@@ -12,7 +12,7 @@ STATS=$(find "$OUT" -name "*kernel_stats.csv" | head -1)
 {
   echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-sub-records $*"
   echo "# bench line:"; tail -1 "$OUT/bench.json"
-  echo "# kernel stats of the WHOLE run (weight load, set_batch autotune launches of every tile shape, warm-up and timed steps):"
+  echo "# kernel stats of the WHOLE run (weight load, set_batch - no autotune launches when the plan table covers the batch -, warm-up and timed steps):"
   python3 - "$STATS" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))

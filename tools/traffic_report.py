@@ -20,6 +20,8 @@ def short(name):
         return "y2::k_conv_i16_splitk<KS=" + n.split("<")[1].split(",")[0] + ">"
     if n.startswith("y2::k_conv_i16_pool<"):
         return "y2::k_conv_i16_pool<...>"
+    if n.startswith("y2::k_conv_i16_w16<"):      # the same layers with 16 channels per wavefront: one family with k_conv_i16
+        return "y2::k_conv_i16<KS=" + n.split("<")[1].split(",")[0] + ",...>"
     if n.startswith("y2::k_conv_i16<"):
         return "y2::k_conv_i16<KS=" + n.split("<")[1].split(",")[0] + ",...>"
     return n

@@ -593,14 +593,14 @@ static int autotune(yolo2_hip_ctx *c)
             float best = 1e30f;
             int bestP = sp->P, bestPad = 0;
             int bestSplit = 0, bestPP = 1, bestW16 = 0, bestHi = 0, bestKs = 0;
-            const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = never, 1 = wherever legal, unset = tuned
+            const char *fs = getenv("YOLO2_SPLITK");   // test hook: 0 = no K-split of either kind, 1 = the lane-split kernel wherever legal, unset = tuned
             // candidates: pixels per lane x workgroups-per-CU cap (160 KiB LDS / cap), and the split-K kernel
             for (int cfgx = 0; cfgx < 18 + 12 + 4; ++cfgx) {   // 18..29: the tile shapes 0..11 again with one accumulator register per channel (form D launches); 30..33: K-split across workgroups, 2 / 4 / 8 / 16 splits
                 const int ks = cfgx >= 30 ? 2 << (cfgx - 30) : 0;
                 const int cfg = ks ? 3 : (cfgx >= 18 ? cfgx - 18 : cfgx);     // (ks: P = 1, no cap)
                 const bool hiacc = cfgx >= 18 && !ks;
                 if (hiacc && (sp->path != 4 || g_no_hiacc)) continue;
-                if (ks && (c->batch > kKsMaxBatch || !c->ks_trip || g_no_ks || (fs && atoi(fs) == 1))) continue;   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14, 15: 4 splits, 2 / 4 pixels per lane; 16, 17: 16 channels per wavefront, 1 / 2 pixels per lane
+                if (ks && (c->batch > kKsMaxBatch || !c->ks_trip || g_no_ks || fs)) continue;   // 0..11: tile shapes; 12, 13: split-K with 4 / 8 splits; 14, 15: 4 splits, 2 / 4 pixels per lane; 16, 17: 16 channels per wavefront, 1 / 2 pixels per lane
                 const bool w16 = cfg >= 16;
                 const int P = w16 ? cfg - 15 : (cfg >= 12 ? 1 : 8 >> (cfg & 3));
                 const int pad = cfg >= 12 ? 0 : ((cfg >> 2) == 0 ? 0 : ((cfg >> 2) == 1 ? 160 * 1024 / 6 : 160 * 1024 / 4));
