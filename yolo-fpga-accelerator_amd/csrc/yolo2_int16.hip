@@ -172,7 +172,7 @@ static bool plan_conv_pool(ConvPlan &p, const ActGeom &gin, const ActGeom &gpool
     const int lt = pool_tile_items_bound(gin);
     if (lt > 12 * 256) return false;
     ConvArgs &a = p.args;
-    p.splitk = 0; p.grp = 1; p.P = 4; p.lds_pad = 0; p.w16 = 0;
+    p.splitk = 0; p.splitk_pp = 1; p.grp = 1; p.P = 4; p.lds_pad = 0; p.w16 = 0; p.hiacc = 0; p.ks = 0;   // the fused kernel has one shape
     p.pool_fused = full ? 2 : 1;
     a.lt_max = lt;
     a.nwin = gin.B * (gin.H / 2) * (gin.W / 2);
