@@ -615,7 +615,10 @@ def main():
                     "frac": used / VALU_PEAK_TCYCLES,
                     "note": "SIMD issue cycles per wave per requant step (4 channels x tap x 64 outputs): form D 12, form C 14, "
                             "form B 16, form A 20 at the measured gfx950 issue costs; peak = 1024 SIMDs x 2.4 GHz. "
-                            "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1)"}
+                            "The int16 path is integer-VALU bound, not HBM bound (DESIGN.md 4.1); the same kernel with staging, barriers, "
+                            "scalar loads and LDS reads compiled out - a pure VALU loop over the step sequence - runs at the same rate "
+                            "(profiles/r03_i16_ablation_b256.txt), and a register-only loop of the sequence costs 13.5 of these cycles per "
+                            "step, not 12 (profiles/r03_ubench_step.txt)"}
         traffic, traffic_src = hbm_traffic_per_launch(key[0], B)
         fam = [l for l in net.CONVS if l.size == key[0] and l.idx not in fused]     # the scope of `traffic`: all k_conv_i16 launches of this kernel size
         fam_alg = sum(conv_layer_bytes(l, Bl) for l in fam) / len(fam)
@@ -632,8 +635,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                         "traffic_scope": f"mean over the {len(fam)} conv{key[0]}x{key[0]} launches per lane and step (autotune may change the "
-                                          "pixels-per-lane instantiation between runs); L2-to-fabric bytes, Infinity Cache hits included",
+                         "traffic_scope": f"mean over the {len(fam)} conv{key[0]}x{key[0]} launches per lane and step (k_conv_i16 and k_conv_i16_w16 "
+                                          "instantiations of that kernel size); L2-to-fabric bytes, Infinity Cache hits included",
                          "algorithmic_bytes_per_launch_same_scope": fam_alg,
                          "algorithmic_bytes_per_launch": g["bytes"] / g["launches"],
                          "binds": False,
