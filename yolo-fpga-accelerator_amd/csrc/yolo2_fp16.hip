@@ -522,8 +522,8 @@ static int make_f16_lanes(yolo2_hip_ctx *c, int want_lanes)
         memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
         l->f16_loaded = true;
         l->f16_plan = new (std::nothrow) F16Plan();
-        ok = l->f16_plan && hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess;
+        ok = l->f16_plan && (i == 0 || (hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) == hipSuccess &&   // lane 0 runs on the caller's stream
+                                        hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess));
         if (ok) l->f16_plan->sw = c->f16_plan->sw;   // a lane runs the parent's kernel selection
     }
     if (!ok) {
@@ -552,16 +552,19 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
             if (rc) return rc;
         }
         const int half = batch / want_lanes;
+        // lanes 1.. on their own streams, lane 0 on the caller's; joins after every lane is enqueued (see yolo2_hip_run_batch_int16)
         HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
-        for (int i = 0; i < want_lanes; ++i) {
+        for (int k = 0; k < want_lanes; ++k) {
+            const int i = (k + 1) % want_lanes;
             yolo2_hip_ctx *l = c->f16_lanes[i];
-            HIP_TRY(hipStreamWaitEvent(l->lane_stream, c->ev_fork, 0), YOLO2_ERROR);
+            hipStream_t ls = i == 0 ? st : l->lane_stream;
+            if (i) HIP_TRY(hipStreamWaitEvent(ls, c->ev_fork, 0), YOLO2_ERROR);
             const int rc = yolo2_hip_run_batch_fp16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
-                                                    region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(float), l->lane_stream);
+                                                    region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(float), ls);
             if (rc) return rc;
-            HIP_TRY(hipEventRecord(l->ev_join, l->lane_stream), YOLO2_ERROR);
-            HIP_TRY(hipStreamWaitEvent(st, l->ev_join, 0), YOLO2_ERROR);
+            if (i) HIP_TRY(hipEventRecord(l->ev_join, ls), YOLO2_ERROR);
         }
+        for (int i = 1; i < want_lanes; ++i) HIP_TRY(hipStreamWaitEvent(st, c->f16_lanes[i]->ev_join, 0), YOLO2_ERROR);
         return YOLO2_SUCCESS;
     }
     int rc = ensure_f16_batch(c, batch);

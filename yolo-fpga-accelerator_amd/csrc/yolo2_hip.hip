@@ -384,9 +384,10 @@ extern "C" int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *c, const uint8_t *con
     const int chunks = (n + batch - 1) / batch;
     auto in_chunk = [&](int k) { return std::min(batch, n - k * batch); };
     auto padded = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t table_bytes = padded((size_t)batch * sizeof(LetterboxItem));   // the chunk's letterbox table leads its staging buffer
     size_t cap = 0;   // bytes of the largest chunk
     for (int k = 0; k < chunks; ++k) {
-        size_t sum = 0;
+        size_t sum = table_bytes;
         for (int i = k * batch; i < k * batch + in_chunk(k); ++i) {
             LetterboxArgs a;
             if (!images[i]) return fail(YOLO2_ERROR, "null image %d", i);
@@ -422,22 +423,27 @@ extern "C" int yolo2_hip_run_images_u8_host(yolo2_hip_ctx *c, const uint8_t *con
     for (int k = 0; k < chunks && rc == YOLO2_SUCCESS; ++k) {
         const int b = k & 1, nf = in_chunk(k), first = k * batch;
         if (k >= 2) drain(k - 2);   // buffer set b is free again once chunk k-2 has left it
-        size_t off = 0;
+        size_t off = table_bytes;
         for (int i = 0; i < nf; ++i) {
             const size_t bytes = (size_t)widths[first + i] * heights[first + i] * channels;
             memcpy(hin[b] + off, images[first + i], bytes);
             offs[(size_t)i] = off;
             off += padded(bytes);
         }
+        LetterboxItem *items = reinterpret_cast<LetterboxItem *>(hin[b]);
+        for (int f = 0; f < batch && rc == YOLO2_SUCCESS; ++f) {   // a partial last chunk repeats its last image
+            const int i = std::min(f, nf - 1);
+            items[f].off = offs[(size_t)i];
+            rc = letterbox_args(widths[first + i], heights[first + i], channels, 416, 416, items[f].a);
+        }
+        if (rc) break;
         Y2_TRY(hipMemcpyAsync(dbytes[b], hin[b], off, hipMemcpyHostToDevice, s_in), YOLO2_DMA_ERROR);
         Y2_TRY(hipEventRecord(e_in[b], s_in), YOLO2_ERROR);
         Y2_TRY(hipStreamWaitEvent(s_run, e_in[b], 0), YOLO2_ERROR);
-        for (int f = 0; f < batch && rc == YOLO2_SUCCESS; ++f) {   // a partial last chunk repeats its last image
-            const int i = std::min(f, nf - 1);
-            rc = yolo2_hip_letterbox_u8((uint64_t)(uintptr_t)(dbytes[b] + offs[(size_t)i]), widths[first + i], heights[first + i],
-                                        channels, (uint64_t)(uintptr_t)(din[b] + (size_t)f * YOLO2_FRAME_ELEMS), 416, 416, s_run);
-        }
-        if (rc == YOLO2_SUCCESS) rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)din[b], batch, (uint64_t)(uintptr_t)dout[b], &q, s_run);
+        hipLaunchKernelGGL(k_letterbox_u8_batch, dim3(blocks_for((long)YOLO2_FRAME_ELEMS, 256), batch), dim3(256), 0, s_run, dbytes[b], din[b],
+                           (int)YOLO2_FRAME_ELEMS);   // the whole chunk in one launch
+        Y2_TRY(hipGetLastError(), YOLO2_ERROR);
+        rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)din[b], batch, (uint64_t)(uintptr_t)dout[b], &q, s_run);
         if (rc) break;
         Y2_TRY(hipEventRecord(e_run[b], s_run), YOLO2_ERROR);
         Y2_TRY(hipStreamWaitEvent(s_out, e_run[b], 0), YOLO2_ERROR);
@@ -499,9 +505,10 @@ extern "C" int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *c, const uint8_t *con
     const int chunks = (n + batch - 1) / batch, cap = cap_per_frame, best_only = (flags & YOLO2_DETS_BEST_CLASS) ? 1 : 0;
     auto in_chunk = [&](int k) { return std::min(batch, n - k * batch); };
     auto padded = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t table_bytes = padded((size_t)batch * sizeof(LetterboxItem));   // the chunk's letterbox table leads its staging buffer
     size_t cap_bytes = 0;   // bytes of the largest chunk
     for (int k = 0; k < chunks; ++k) {
-        size_t sum = 0;
+        size_t sum = table_bytes;
         for (int i = k * batch; i < k * batch + in_chunk(k); ++i) {
             LetterboxArgs a;
             if (!images[i]) return fail(YOLO2_ERROR, "null image %d", i);
@@ -539,30 +546,37 @@ extern "C" int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *c, const uint8_t *con
     for (int k = 0; k < chunks && rc == YOLO2_SUCCESS; ++k) {
         const int b = k & 1, nf = in_chunk(k), first = k * batch;
         if (k >= 2) drain(k - 2);   // buffer set b is free again once chunk k-2 has left it
-        size_t off = 0;
+        size_t off = table_bytes;
         for (int i = 0; i < nf; ++i) {
             const size_t bytes = (size_t)widths[first + i] * heights[first + i] * channels;
             memcpy(P.hin[b] + off, images[first + i], bytes);
             offs[(size_t)i] = off;
             off += padded(bytes);
         }
-        for (int f = 0; f < batch; ++f) { const int i = std::min(f, nf - 1); cw[(size_t)f] = widths[first + i]; chh[(size_t)f] = heights[first + i]; }
+        LetterboxItem *items = reinterpret_cast<LetterboxItem *>(P.hin[b]);
+        for (int f = 0; f < batch; ++f) {   // a partial last chunk repeats its last image
+            const int i = std::min(f, nf - 1);
+            cw[(size_t)f] = widths[first + i]; chh[(size_t)f] = heights[first + i];
+            items[f].off = offs[(size_t)i];
+            if ((rc = letterbox_args(widths[first + i], heights[first + i], channels, 416, 416, items[f].a))) break;
+        }
+        if (rc) break;
         if ((rc = y2_post_fill_geom(P.hgeom[b], cw.data(), chh.data(), batch))) break;
         Y2_TRY(hipMemcpyAsync(P.dbytes[b], P.hin[b], off, hipMemcpyHostToDevice, P.s_in), YOLO2_DMA_ERROR);
         Y2_TRY(hipMemcpyAsync(P.post[b].geom, P.hgeom[b], (size_t)batch * gbytes, hipMemcpyHostToDevice, P.s_in), YOLO2_DMA_ERROR);
         Y2_TRY(hipEventRecord(P.e_in[b], P.s_in), YOLO2_ERROR);
         Y2_TRY(hipStreamWaitEvent(P.s_run, P.e_in[b], 0), YOLO2_ERROR);
-        for (int f = 0; f < batch && rc == YOLO2_SUCCESS; ++f) {   // a partial last chunk repeats its last image
-            const int i = std::min(f, nf - 1);
-            rc = yolo2_hip_letterbox_u8((uint64_t)(uintptr_t)(P.dbytes[b] + offs[(size_t)i]), widths[first + i], heights[first + i], channels,
-                                        (uint64_t)(uintptr_t)(P.din[b] + (size_t)f * YOLO2_FRAME_ELEMS), 416, 416, P.s_run);
-        }
-        if (rc == YOLO2_SUCCESS) rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)P.din[b], batch, (uint64_t)(uintptr_t)P.dout[b], &q, P.s_run);
-        // the step after the path, on the device that produced the tensor, straight from HBM
-        if (rc == YOLO2_SUCCESS) rc = y2_post_enqueue_int16(c->device, P.dout[b], batch, q, thresh, nms, cap, best_only, &P.post[b], P.s_run);
+        hipLaunchKernelGGL(k_letterbox_u8_batch, dim3(blocks_for((long)YOLO2_FRAME_ELEMS, 256), batch), dim3(256), 0, P.s_run, P.dbytes[b], P.din[b],
+                           (int)YOLO2_FRAME_ELEMS);
+        Y2_TRY(hipGetLastError(), YOLO2_ERROR);
+        rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)P.din[b], batch, (uint64_t)(uintptr_t)P.dout[b], &q, P.s_run);
         if (rc) break;
         Y2_TRY(hipEventRecord(P.e_run[b], P.s_run), YOLO2_ERROR);
+        // the step after the path, on the device that produced the tensor, straight from HBM - on the download stream, so that the
+        // next chunk's letterbox and network follow this chunk's network at once (the tail is 64 workgroups for 0.7 ms: latency, not work)
         Y2_TRY(hipStreamWaitEvent(P.s_out, P.e_run[b], 0), YOLO2_ERROR);
+        rc = y2_post_enqueue_int16(c->device, P.dout[b], batch, q, thresh, nms, cap, best_only, &P.post[b], P.s_out);
+        if (rc) break;
         Y2_TRY(hipMemcpyAsync(P.hcounts[b], P.post[b].counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, P.s_out), YOLO2_DMA_ERROR);
         Y2_TRY(hipMemcpyAsync(P.hdets[b], P.post[b].dets, (size_t)batch * cap * sizeof(yolo2_hip_det), hipMemcpyDeviceToHost, P.s_out), YOLO2_DMA_ERROR);
         Y2_TRY(hipEventRecord(P.e_out[b], P.s_out), YOLO2_ERROR);
