@@ -435,9 +435,13 @@ void run_stream(AppConfig cfg)
         try {
             int taken = 0;
             bool more = true;
+            // the first chunks are short (one batch per device, then doubling): the accelerator starts after 64 decoded images, not 512
+            int want = std::min(chunk, cfg.batch * (int)cfg.devices.size());
             while (more) {
                 auto ck = std::make_unique<Chunk>();
-                while ((int)ck->frames.size() < chunk && (cfg.max_frames <= 0 || taken + (int)ck->frames.size() < cfg.max_frames)) {
+                const int this_chunk = want;
+                want = std::min(chunk, want * 2);
+                while ((int)ck->frames.size() < this_chunk && (cfg.max_frames <= 0 || taken + (int)ck->frames.size() < cfg.max_frames)) {
                     SrcFrame f;
                     if (!src.next_ref(f)) { more = false; break; }
                     ck->frames.push_back(std::move(f));
