@@ -1552,14 +1552,13 @@ __global__ void k_pack_weights_f16(const float *__restrict__ src, _Float16 *__re
 // w0: [27][32] fp32 (k = c*9 + tap), bias0: [32] fp32; out = layer-1 items of 32 halves.
 __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict__ frames, const float *__restrict__ w0,
                                                           const float *__restrict__ bias0, _Float16 *__restrict__ out, int H,
-                                                          int W, int oWp, int oPL)
+                                                          int W, int oWp, int oPL, int n_tile_total)
 {
     constexpr int TR = 16, TC = 32, PR = TR + 2, PC = TC + 2, PCS = 36;   // patch rows / cols / row stride (halves)
     __shared__ _Float16 patch[3 * PR * PCS];
+    __shared__ __attribute__((aligned(16))) _Float16 otile[8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W / TC, tiles_y = H / TR;
-    const int b = blockIdx.x / (tiles_x * tiles_y), tr = blockIdx.x % (tiles_x * tiles_y);
-    const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
 
     // B fragments (weights), constant for the whole kernel: lane (n = lane & 31, h = lane >> 5) holds B[16kk + 8h + j][n]
     const int n = lane & 31, h = lane >> 5;
@@ -1575,63 +1574,79 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             aoff[kk][j] = k < 27 ? (c * PR + tap / 3) * PCS + tap % 3 : 0;
         }
     const float bv = bias0[n];
+    // this lane's pixel inside an MFMA block: row r = 4*pc + 2*dy + dx
+    const int r = lane & 31, dx = r & 1, dy = (r >> 1) & 1, pc = r >> 2;
 
-    // stage the patch: rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32, zero outside the image.  All of a
-    // thread's loads are issued before the first conversion (clamped addresses, masked afterwards).
-    const float *fb = frames + (size_t)b * 3 * H * W;
+    // The workgroup is PERSISTENT (round 3): it walks tiles blockIdx.x, + gridDim.x, ... and requests tile t + 1's patch
+    // (registers) right after tile t's has been written to LDS, so the loads are in flight during tile t's gathers, MFMAs and
+    // stores.  One tile per workgroup kept only a quarter of a workgroup's life's worth of bytes in flight: 2.2 TB/s.
     constexpr int NEL = 3 * PR * PC, NIT = (NEL + 255) / 256;
-    float pv[NIT];
+    // patch element i of this thread (the same for every tile): plane c, patch row py, patch column px
+    int pel_off[NIT], pel_pk[NIT];   // LDS offset; py | px << 8 | c << 16
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = min(tid + it * 256, NEL - 1);
         const int c = i / (PR * PC), r2 = i - c * (PR * PC), py = r2 / PC, px = r2 - py * PC;
-        const int sy = ty0 + py - 1, sx = tx0 + px - 1;
-        pv[it] = fb[((size_t)c * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)];
+        pel_pk[it] = py | (px << 8) | (c << 16);
+        pel_off[it] = (c * PR + py) * PCS + px;
     }
+    float pv[NIT];
+    auto request = [&](int tile) {   // rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32; clamped addresses, masked when written
+        const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
+        const float *fb = frames + (size_t)b * 3 * H * W;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int i = tid + it * 256;
-        if (i < NEL) {
-            const int c = i / (PR * PC), r2 = i - c * (PR * PC), py = r2 / PC, px = r2 - py * PC;
-            const int sy = ty0 + py - 1, sx = tx0 + px - 1;
-            patch[(c * PR + py) * PCS + px] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? (_Float16)pv[it] : (_Float16)0.f;
+        for (int it = 0; it < NIT; ++it) {
+            const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 + ((pel_pk[it] >> 8) & 255) - 1;
+            pv[it] = fb[((size_t)(pel_pk[it] >> 16) * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)];
         }
-    }
-    __syncthreads();
+    };
+    if ((int)blockIdx.x < n_tile_total) request((int)blockIdx.x);
+    for (int tile = (int)blockIdx.x; tile < n_tile_total; tile += (int)gridDim.x) {
+        const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
+        const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            if (i < NEL) {
+                const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 + ((pel_pk[it] >> 8) & 255) - 1;
+                patch[pel_off[it]] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? (_Float16)pv[it] : (_Float16)0.f;
+            }
+        }
+        __syncthreads();   // the patch is complete; everybody has stored the previous tile's pooled rows
+        if (tile + (int)gridDim.x < n_tile_total) request(tile + (int)gridDim.x);
 
-    // this lane's pixel inside an MFMA block: row r = 4*pc + 2*dy + dx
-    const int r = lane & 31, dx = r & 1, dy = (r >> 1) & 1, pc = r >> 2;
-    __shared__ __attribute__((aligned(16))) _Float16 otile[8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int prow = wave * 2 + (mb >> 1), chalf = mb & 1;            // pooled row 0..7, column half 0..1 of the tile
-        const int base = (2 * prow + dy) * PCS + (chalf * 16 + 2 * pc + dx);   // top-left tap of this lane's conv pixel
-        float16_t acc;
+        for (int mb = 0; mb < 4; ++mb) {
+            const int prow = wave * 2 + (mb >> 1), chalf = mb & 1;            // pooled row 0..7, column half 0..1 of the tile
+            const int base = (2 * prow + dy) * PCS + (chalf * 16 + 2 * pc + dx);   // top-left tap of this lane's conv pixel
+            float16_t acc;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8_t af;
+            for (int kk = 0; kk < 2; ++kk) {
+                half8_t af;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) af[j] = patch[base + aoff[kk][j]];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[kk], acc, 0, 0, 0);
+                for (int j = 0; j < 8; ++j) af[j] = patch[base + aoff[kk][j]];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[kk], acc, 0, 0, 0);
+            }
+            // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
+                if (v < 0.f) v *= 0.1f;
+                otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
+            }
         }
-        // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
+        __syncthreads();   // the pooled tile is complete; nobody reads the patch any more
+        // 128 pooled pixels x 4 chunks of 8 channels = 512 16-byte stores, two per thread
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
-            if (v < 0.f) v *= 0.1f;
-            otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
+        for (int it = 0; it < 2; ++it) {
+            const int e = tid + it * 256, pp = e >> 2, ck = e & 3;
+            const int oy = ty0 / 2 + (pp >> 4), ox = tx0 / 2 + (pp & 15);
+            *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + ck * 8) =
+                *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
         }
-    }
-    __syncthreads();
-    // 128 pooled pixels x 4 chunks of 8 channels = 512 16-byte stores, two per thread
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int e = tid + it * 256, pp = e >> 2, ck = e & 3;
-        const int oy = ty0 / 2 + (pp >> 4), ox = tx0 / 2 + (pp & 15);
-        *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + ck * 8) =
-            *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
     }
 }
 

@@ -87,6 +87,10 @@ void y2_f16_plan_free(yolo2_hip_ctx *c)
 // passed as its output: full-resolution offsets (104 x 104 planes) into a 52 x 52 tensor = an out-of-bounds store, a GPU memory
 // fault and an abort inside run_batch_fp16.  This check turns that class of mistake into YOLO2_ERROR before
 // anything is launched; yolo2_hip_f16_store_check exposes it so that it can be tested without a GPU.
+#ifndef Y2_CONV0_WGS
+#define Y2_CONV0_WGS 6
+#endif
+
 static int f16_store_check(const char *kernel, int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store,
                            int oWp, int oPL, int npix, int npool, int dst_B, int dst_H, int dst_W, int dst_Cp)
 {
@@ -249,7 +253,7 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
         (void)frames; (void)region;                                                                    \
         __VA_ARGS__;                                                                                   \
     }
-Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL))
+Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL, s.T))
 Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
 template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
@@ -290,7 +294,8 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         s.block = dim3(256);
         if (!sw.no_mfma0) {   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
             s.kernel = "k_conv0_pool_mfma"; s.launch = L_conv0_mfma;
-            s.grid = dim3((unsigned)B * (416 / 16) * (416 / 32));
+            s.T = B * (416 / 16) * (416 / 32);
+            s.grid = dim3((unsigned)std::min(s.T, 256 * Y2_CONV0_WGS));   // persistent workgroups, Y2_CONV0_WGS per CU
         } else {
             s.kernel = "k_conv0_pool_f16"; s.launch = L_conv0_valu;
             s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
