@@ -1016,3 +1016,65 @@ def test_fp32_tiled_batch_bit_exact(P, monkeypatch):
     one = ctx.run_batch_fp32_host(frames[2:3])
     assert np.array_equal(u(one[0]), u(got[2]))
     ctx.close()
+
+
+# ---- the plan table (config/plan_gfx950.txt): loaded once per process, so every case runs in a process of its own
+
+def _plan_probe(env_extra, batch=3):
+    """A fresh process: load the synthetic model, plan `batch`, run it; returns the per-layer plan strings and whether frame 0
+    equals the reference fixture."""
+    import json, subprocess, sys
+    code = (
+        "import sys, json, numpy as np\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'yolo-fpga-accelerator_amd')!r})\n"
+        "from yolo2_amd import hipdrv, synth, net\n"
+        "m = synth.SynthModel(seed=1); ctx = hipdrv.Yolo2Hip(0); ctx.load_model(m)\n"
+        f"ctx.set_batch({batch})\n"
+        f"r, _ = ctx.run_batch_host(np.concatenate([synth.frames(7, 1)] * {batch}))\n"
+        f"want = np.load({os.path.join(ROOT, 'tests', 'golden', 'fullnet.npz')!r})['i16/std/region_raw_i16'].reshape(425, 13, 13)\n"
+        "print('PROBE ' + json.dumps({'plans': [ctx.conv_plan(l.ord) for l in net.CONVS], 'ok': bool(np.array_equal(r[0], want) and np.array_equal(r[-1], want))}))\n")
+    env = dict(os.environ)
+    for k in ("YOLO2_PLAN_FILE", "YOLO2_PLAN_WRITE", "YOLO2_AUTOTUNE"):
+        env.pop(k, None)
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("PROBE ")][-1]
+    return json.loads(line[6:])
+
+
+def test_plan_table_gives_every_process_the_same_plan():
+    """set_batch's autotune picked different kernels from run to run.  With the committed table two processes plan a
+    listed batch identically (and without timing anything), and the result is the fixture's."""
+    a, b = _plan_probe({}), _plan_probe({})
+    assert a["ok"] and b["ok"]
+    assert a["plans"] == b["plans"]
+    assert len(a["plans"]) == 23 and all(p.startswith("P=") for p in a["plans"])
+
+
+def test_damaged_plan_table_costs_time_not_correctness(tmp_path):
+    """Lines outside the planner's ranges are dropped, a batch with a missing or refused launch is autotuned: garbage, out-of-range
+    fields, a table whose arithmetic forms belong to another model and a half-written table all end in a correct run."""
+    good = [l for l in open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "config", "plan_gfx950.txt")) if l.split()[:1] == ["3"]]
+    assert len(good) >= 23
+    cases = {
+        "garbage": "hello\n3 0 0\n\x00\x01\n" + "3 1 2 3\n" * 5,
+        "out_of_range": "".join(f"3 {l.idx} 0 4 7 12345 3 9 2 5 -1 6\n" for l in net.CONVS),
+        "other_forms": "".join(" ".join(f[:3] + ["0"] + f[4:]) + "\n" for f in (l.split() for l in good)),   # form A everywhere
+        "eight_pixels_everywhere": "".join(" ".join(f[:4] + ["8"] + f[5:]) + "\n" for f in (l.split() for l in good)),
+        "half": "".join(good[:11]),
+    }
+    for name, text in cases.items():
+        f = tmp_path / f"{name}.txt"
+        f.write_text(text)
+        r = _plan_probe({"YOLO2_PLAN_FILE": str(f)})
+        assert r["ok"], name
+
+
+def test_recorded_plan_round_trips(tmp_path):
+    """YOLO2_AUTOTUNE=1 + YOLO2_PLAN_WRITE record what the autotune picked; a process given that file plans exactly that."""
+    f = tmp_path / "plan.txt"
+    a = _plan_probe({"YOLO2_AUTOTUNE": "1", "YOLO2_PLAN_WRITE": str(f)}, batch=5)
+    assert a["ok"] and f.exists() and len(f.read_text().splitlines()) >= 23
+    b = _plan_probe({"YOLO2_PLAN_FILE": str(f)}, batch=5)
+    assert b["ok"] and b["plans"] == a["plans"]

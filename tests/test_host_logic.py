@@ -269,3 +269,35 @@ def test_fp16_launch_path_reads_no_environment():
     sel, run = body[:body.index("P.batch = B;")], body[body.index('extern "C" int yolo2_hip_run_batch_fp16('):]
     assert "getenv" not in sel and "getenv" not in run
     assert src.count("from_env()") >= 2 and "getenv" in src[src.index("static F16Switches from_env"):src.index("struct F16Step;")]
+
+
+def test_committed_plan_table_is_well_formed():
+    """config/plan_gfx950.txt (csrc/yolo2_int16.hip "the plan table") replaces the per-process autotune for the batches it holds.
+    The loader drops any line outside what the planner can produce and autotunes a batch with a missing launch, so a damaged
+    table costs time, not correctness - but the committed one must be complete: every listed batch has a line for launch 0 of
+    all 23 conv layers, every field is in the planner's range, the bench's batch (64 = lanes of 21 + 21 + 22) and the
+    single frame are there."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "yolo-fpga-accelerator_amd"))
+    from yolo2_amd import net
+    rows = {}
+    for ln in open(os.path.join(root, "yolo-fpga-accelerator_amd", "config", "plan_gfx950.txt")):
+        if ln.startswith("#") or not ln.strip():
+            continue
+        v = [int(x) for x in ln.split()]
+        assert len(v) == 12, ln
+        B, L, S, path, P, pad, splitk, pp, w16, fuse, hiacc, ks = v
+        assert B > 0 and 0 <= L < 32 and 0 <= S <= 8 and path in (0, 1, 2, 3, 4) and P in (1, 2, 4, 8), ln
+        assert pad in (0, 160 * 1024 // 6, 160 * 1024 // 4) and splitk in (0, 4, 8) and pp in (1, 2, 4), ln
+        assert w16 in (0, 1) and fuse in (0, 1) and hiacc in (0, 1) and ks in (0, 2, 4, 8, 16), ln
+        assert not (ks and (splitk or w16 or hiacc)) and not (splitk and w16), ln     # one kernel per launch
+        assert not fuse or (L in (0, 2, 6, 10, 16) and S == 0), ln                    # only the convs in front of a pool fuse
+        assert not ks or B <= 4, ln                                                   # the triple scratch exists for batches <= 4
+        rows[(B, L, S)] = v
+    convs = [l.idx for l in net.LAYERS if l.type == net.CONV]
+    batches = sorted({k[0] for k in rows})
+    assert {1, 21, 22, 64, 128, 256} <= set(batches), batches
+    for B in batches:
+        assert all((B, L, 0) in rows for L in convs), B
+        for (b, L, S) in rows:
+            assert b != B or S == 0 or (b, L, S - 1) in rows      # launches of a layer are numbered without holes

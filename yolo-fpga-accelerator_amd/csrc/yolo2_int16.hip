@@ -711,6 +711,12 @@ void load_plan_table()
         pl.hiacc = pl.ks = 0;
         if (line[0] == '#' || sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d %d", &B, &L, &S, &pl.path, &pl.P, &pl.pad, &pl.splitk, &pl.pp, &pl.w16, &pl.fuse,
                                      &pl.hiacc, &pl.ks) < 10) continue;
+        // a line outside what the planner itself can produce is dropped here (its batch then misses a launch and is autotuned)
+        auto one_of = [](int v, std::initializer_list<int> ok) { for (int o : ok) if (v == o) return true; return false; };
+        if (B <= 0 || L < 0 || L >= 32 || S < 0 || S > 8 || !one_of(pl.path, {0, 1, 2, 3, 4}) || !one_of(pl.P, {1, 2, 4, 8}) ||
+            !one_of(pl.pad, {0, 160 * 1024 / 6, 160 * 1024 / 4}) || !one_of(pl.splitk, {0, 4, 8}) || !one_of(pl.pp, {1, 2, 4}) ||
+            !one_of(pl.w16, {0, 1}) || !one_of(pl.fuse, {0, 1}) || !one_of(pl.hiacc, {0, 1}) || !one_of(pl.ks, {0, 2, 4, 8, 16}))
+            continue;
         if (!g_plans.lines.count({B, {L, S}})) g_plans.per_batch[B]++;
         g_plans.lines[{B, {L, S}}] = pl;       // a later line for the same key wins (appended re-measurements)
     }
@@ -753,7 +759,10 @@ static int apply_plan_table(yolo2_hip_ctx *c, bool *known)
             const PlanLine &pl = todo[k].second;
             sp->lds_pad = pl.pad; sp->splitk = pl.splitk; sp->splitk_pp = pl.pp; sp->w16 = pl.w16; sp->hiacc = pl.hiacc; sp->ks = pl.ks;
             plan_conv(*sp, tin.g, tout.g.cg_stride, out_base, (kNet[i].n + 3) / 4, pl.P);
-            if (sp->P != pl.P && !sp->splitk) return fail(YOLO2_ERROR, "plan table: layer %d cannot run %d pixels per lane at batch %d", i, pl.P, c->batch);
+            if (sp->P != pl.P && !sp->splitk) {   // the planner refused the line (a table made for another build): time the candidates instead
+                if (getenv("YOLO2_VERBOSE")) fprintf(stderr, "[yolo2_hip] plan table: layer %d cannot run %d pixels per lane at batch %d - autotuning\n", i, pl.P, c->batch);
+                return YOLO2_SUCCESS;
+            }
         }
     }
     // conv + pool fusion as the table says (legality re-checked: an illegal line falls back to separate kernels)
