@@ -191,6 +191,14 @@ void y2_free_activations(yolo2_hip_ctx *c);
 void y2_free_f16_activations(yolo2_hip_ctx *c);
 void y2_free_f32_activations(yolo2_hip_ctx *c);
 void y2_destroy_lanes(yolo2_hip_ctx *c);
+// Streams of the lanes (yolo2_hip.hip): created at the device's HIGHEST stream priority.  HIP multiplexes the streams of a process
+// onto a few hardware queues PER PRIORITY LEVEL (4 by default); at the default priority the lanes share that pool with every other
+// stream of the process - the streaming entries' copy streams, torch's and RCCL's internal streams - and two lanes that land on one
+// queue run one after the other (measured: -5 % under torch.distributed, -10 % in the streaming entry).  At their own level the
+// lanes have a pool to themselves.  own_stream_for_lane0 = false (YOLO2_LANE_PRIORITY=0, the round-3 interim design): default
+// priority, lane 0 runs on the caller's stream.
+int y2_lane_stream_create(hipStream_t *s);
+bool y2_lane0_own_stream();
 int y2_ensure_prof_events(yolo2_hip_ctx *c);
 int y2_ensure(void **p, size_t *cap, size_t need);   // grow-only device scratch
 

@@ -527,8 +527,8 @@ static int make_f16_lanes(yolo2_hip_ctx *c, int want_lanes)
         memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
         l->f16_loaded = true;
         l->f16_plan = new (std::nothrow) F16Plan();
-        ok = l->f16_plan && (i == 0 || (hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) == hipSuccess &&   // lane 0 runs on the caller's stream
-                                        hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess));
+        ok = l->f16_plan && ((i == 0 && !y2_lane0_own_stream()) || (y2_lane_stream_create(&l->lane_stream) == YOLO2_SUCCESS &&
+                                                                     hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) == hipSuccess));
         if (ok) l->f16_plan->sw = c->f16_plan->sw;   // a lane runs the parent's kernel selection
     }
     if (!ok) {
@@ -562,14 +562,15 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
         for (int k = 0; k < want_lanes; ++k) {
             const int i = (k + 1) % want_lanes;
             yolo2_hip_ctx *l = c->f16_lanes[i];
-            hipStream_t ls = i == 0 ? st : l->lane_stream;
-            if (i) HIP_TRY(hipStreamWaitEvent(ls, c->ev_fork, 0), YOLO2_ERROR);
+            hipStream_t ls = l->lane_stream ? l->lane_stream : st;
+            if (l->lane_stream) HIP_TRY(hipStreamWaitEvent(ls, c->ev_fork, 0), YOLO2_ERROR);
             const int rc = yolo2_hip_run_batch_fp16(l, frames_dev + (uint64_t)i * half * YOLO2_FRAME_ELEMS * sizeof(float), half,
                                                     region_dev + (uint64_t)i * half * YOLO2_REGION_ELEMS * sizeof(float), ls);
             if (rc) return rc;
-            if (i) HIP_TRY(hipEventRecord(l->ev_join, ls), YOLO2_ERROR);
+            if (l->lane_stream) HIP_TRY(hipEventRecord(l->ev_join, ls), YOLO2_ERROR);
         }
-        for (int i = 1; i < want_lanes; ++i) HIP_TRY(hipStreamWaitEvent(st, c->f16_lanes[i]->ev_join, 0), YOLO2_ERROR);
+        for (int i = 0; i < want_lanes; ++i)
+            if (c->f16_lanes[i]->lane_stream) HIP_TRY(hipStreamWaitEvent(st, c->f16_lanes[i]->ev_join, 0), YOLO2_ERROR);
         return YOLO2_SUCCESS;
     }
     int rc = ensure_f16_batch(c, batch);

@@ -244,6 +244,22 @@ static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch)
     return YOLO2_SUCCESS;
 }
 
+static const bool g_lane_prio = !(getenv("YOLO2_LANE_PRIORITY") && atoi(getenv("YOLO2_LANE_PRIORITY")) == 0);   // latched: set_batch time only
+
+bool y2_lane0_own_stream() { return g_lane_prio; }
+
+int y2_lane_stream_create(hipStream_t *s)
+{
+    if (!g_lane_prio) {
+        HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking), YOLO2_ERROR);
+        return YOLO2_SUCCESS;
+    }
+    int least = 0, greatest = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), YOLO2_ERROR);   // numerically lower = higher priority
+    HIP_TRY(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
 extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
 {
     if (!c) return;

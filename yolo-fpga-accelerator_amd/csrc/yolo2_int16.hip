@@ -896,9 +896,7 @@ static int make_lane(yolo2_hip_ctx *p, bool own_stream, yolo2_hip_ctx **out)
     l->bias_q = p->bias_q;
     l->act_q = p->act_q;
     int rc = resolve_q(l);
-    // (lane 0 runs on the caller's stream and gets none of its own: every stream of the process takes a share of the few hardware
-    //  queues, and an idle one still pushes a busy one onto a queue somebody else uses)
-    if (rc == YOLO2_SUCCESS && own_stream && hipStreamCreateWithFlags(&l->lane_stream, hipStreamNonBlocking) != hipSuccess) rc = fail(YOLO2_ERROR, "hipStreamCreate failed");
+    if (rc == YOLO2_SUCCESS && own_stream) rc = y2_lane_stream_create(&l->lane_stream);
     if (rc == YOLO2_SUCCESS && own_stream && hipEventCreateWithFlags(&l->ev_join, hipEventDisableTiming) != hipSuccess) rc = fail(YOLO2_ERROR, "hipEventCreate failed");
     if (rc) { yolo2_hip_destroy(l); return rc; }
     l->weights_loaded = true;
@@ -941,7 +939,7 @@ extern "C" int yolo2_hip_set_batch(yolo2_hip_ctx *c, int batch)
             for (int x : v) sum += x;
             if ((int)v.size() == nl && sum == batch) frames = v[i];
         }
-        int rc = make_lane(c, i > 0, &l);
+        int rc = make_lane(c, i > 0 || y2_lane0_own_stream(), &l);
         if (rc == YOLO2_SUCCESS) {
             c->lanes.push_back(l);
             c->lane_first.push_back(first);
@@ -1100,25 +1098,26 @@ extern "C" int yolo2_hip_run_batch_int16(yolo2_hip_ctx *c, uint64_t frames_dev, 
     }
     hipStream_t st = (hipStream_t)stream;
     if (c->laned) {
-        // Fork the part-batches: lanes 1.. on their own streams behind an event on the caller's stream, lane 0 on the caller's stream
-        // itself, and the joins only after EVERY lane is enqueued.  HIP multiplexes streams onto a few hardware queues (4 by
-        // default): with a join wait of the caller's stream enqueued between two lanes, a later lane that shares the caller's
-        // hardware queue sat behind that wait until the earlier lane had finished (kernel trace of the streaming entry, whose copy
-        // streams take two of the queues: one lane started 12 ms into a 22 ms step).  One stream fewer also leaves a queue free.
+        // Fork the part-batches onto the lane streams behind an event on the caller's stream; the joins only after EVERY lane is
+        // enqueued.  HIP multiplexes streams onto a few hardware queues: with a join wait of the caller's stream enqueued between
+        // two lanes, a later lane that shared the caller's hardware queue sat behind that wait until the earlier lane had finished
+        // (kernel trace of the streaming entry: one lane started 12 ms into a 22 ms step).  The lane streams themselves live at
+        // the highest stream priority, which has a hardware-queue pool of its own (y2_lane_stream_create).
         const int nl = (int)c->lanes.size();
         HIP_TRY(hipEventRecord(c->ev_fork, st), YOLO2_ERROR);
         for (int k = 0; k < nl; ++k) {
-            const int i = (k + 1) % nl;             // lanes 1 .. nl-1, then lane 0
+            const int i = (k + 1) % nl;             // lanes 1 .. nl-1, then lane 0 (which runs on the caller's stream when it has none)
             yolo2_hip_ctx *l = c->lanes[i];
-            hipStream_t ls = i == 0 ? st : l->lane_stream;
+            hipStream_t ls = l->lane_stream ? l->lane_stream : st;   // a lane without a stream of its own runs on the caller's
             const uint64_t first = (uint64_t)c->lane_first[i];
-            if (i) HIP_TRY(hipStreamWaitEvent(ls, c->ev_fork, 0), YOLO2_ERROR);
+            if (l->lane_stream) HIP_TRY(hipStreamWaitEvent(ls, c->ev_fork, 0), YOLO2_ERROR);
             const int rc = yolo2_hip_run_batch_int16(l, frames_dev + first * YOLO2_FRAME_ELEMS * sizeof(float), l->batch,
                                                      region_dev + first * YOLO2_REGION_ELEMS * sizeof(int16_t), final_q, ls);
             if (rc) return rc;
-            if (i) HIP_TRY(hipEventRecord(l->ev_join, ls), YOLO2_ERROR);
+            if (l->lane_stream) HIP_TRY(hipEventRecord(l->ev_join, ls), YOLO2_ERROR);
         }
-        for (int i = 1; i < nl; ++i) HIP_TRY(hipStreamWaitEvent(st, c->lanes[i]->ev_join, 0), YOLO2_ERROR);
+        for (int i = 0; i < nl; ++i)
+            if (c->lanes[i]->lane_stream) HIP_TRY(hipStreamWaitEvent(st, c->lanes[i]->ev_join, 0), YOLO2_ERROR);
         c->final_q = c->lanes[0]->final_q;
         return YOLO2_SUCCESS;
     }
