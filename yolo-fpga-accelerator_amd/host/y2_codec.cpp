@@ -383,7 +383,7 @@ struct Jpeg {
             const int t = br.symbol(hd);
             if (t > 16) bad("Corrupt JPEG: bad huffman code");
             c.dc_pred += br.extend(t);
-            d[0] = (int16_t)(c.dc_pred << al);
+            d[0] = (int16_t)((unsigned)c.dc_pred << al);   // (shifted as unsigned: the value may be negative; same low 16 bits)
         } else if (br.bit()) {
             d[0] = (int16_t)(d[0] + (1 << al));
         }
@@ -414,7 +414,7 @@ struct Jpeg {
                 } else {
                     k += r;
                     if (k > 63) bad("Corrupt JPEG: bad huffman code");
-                    d[kZigzag[k++]] = (int16_t)(br.extend(s) << al);
+                    d[kZigzag[k++]] = (int16_t)((unsigned)br.extend(s) << al);
                 }
             }
             return;
@@ -704,9 +704,14 @@ struct Inflate {
     uint32_t acc = 0;
     int n = 0;
     std::vector<uint8_t> out;
+    size_t limit = (size_t)-1;   // bytes the caller can use: decoding stops there (a damaged stream cannot inflate without bound)
+    int past_end = 0;            // zero bytes supplied after the end of the input (the reference's loader feeds zeros too)
     int bits(int k)
     {
-        while (n < k) { acc |= (uint32_t)(p < end ? *p++ : 0) << n; n += 8; }
+        while (n < k) {
+            if (p >= end && ++past_end > 8) bad("Corrupt PNG: zlib stream ends early");
+            acc |= (uint32_t)(p < end ? *p++ : 0) << n; n += 8;
+        }
         const int v = (int)(acc & ((1u << k) - 1));
         acc >>= k; n -= k;
         return v;
@@ -743,6 +748,7 @@ struct Inflate {
                 const int len = hdr[0] | (hdr[1] << 8), nlen = hdr[2] | (hdr[3] << 8);
                 if (nlen != (len ^ 0xffff)) bad("Corrupt PNG: zlib corrupt");
                 for (int i = 0; i < len; ++i) out.push_back((uint8_t)bits(8));
+                if (out.size() >= limit) return;
                 continue;
             }
             if (type == 3) bad("Corrupt PNG: bad block type");
@@ -778,7 +784,11 @@ struct Inflate {
             }
             for (;;) {
                 const int s = decode(lit);
-                if (s < 256) { out.push_back((uint8_t)s); continue; }
+                if (s < 256) {
+                    out.push_back((uint8_t)s);
+                    if (out.size() >= limit) return;
+                    continue;
+                }
                 if (s == 256) break;
                 if (s > 285) bad("Corrupt PNG: bad huffman code");
                 const int len = len_base[s - 257] + bits(len_extra[s - 257]);
@@ -788,6 +798,7 @@ struct Inflate {
                 if (back > out.size()) bad("Corrupt PNG: bad dist");
                 const size_t from = out.size() - back;
                 for (int i = 0; i < len; ++i) out.push_back(out[from + (size_t)i]);
+                if (out.size() >= limit) return;
             }
         }
     }
@@ -887,7 +898,9 @@ ImageU8 decode_png_bytes(const uint8_t *data, size_t n)
     if (idat.empty()) bad("Corrupt PNG: no IDAT");
     Inflate z;
     z.p = idat.data(); z.end = idat.data() + idat.size();
-    z.out.reserve(((size_t)W * depth * 4 / 8 + 2) * H);
+    // the most bytes any layout of this image can hold: every Adam7 pass has at most H rows of at most the full row + filter byte
+    z.limit = ((size_t)W * depth * 4 / 8 + 2) * ((size_t)H + 7) * (interlace ? 2 : 1);
+    z.out.reserve(std::min<size_t>(z.limit, (size_t)64 << 20));
     z.run(!iphone);
 
     const int chans = color == 3 ? 1 : ((color & 2 ? 3 : 1) + (color & 4 ? 1 : 0));

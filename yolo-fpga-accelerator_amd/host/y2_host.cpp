@@ -195,7 +195,7 @@ ImageU8 load_pnm_u8(const std::string &path)
     }
     const int chans = magic[1] == '6' ? 3 : 1;
     const int w = pnm_int(f), h = pnm_int(f), maxv = pnm_int(f);
-    if (w <= 0 || h <= 0 || maxv != 255) {
+    if (w <= 0 || h <= 0 || maxv != 255 || (long long)w * h > (1LL << 28)) {   // (the letterbox entry's own size limit)
         fclose(f);
         throw std::runtime_error("Bad PNM header: " + path);
     }
