@@ -1032,7 +1032,7 @@ def _plan_probe(env_extra, batch=3):
         f"ctx.set_batch({batch})\n"
         f"r, _ = ctx.run_batch_host(np.concatenate([synth.frames(7, 1)] * {batch}))\n"
         f"want = np.load({os.path.join(ROOT, 'tests', 'golden', 'fullnet.npz')!r})['i16/std/region_raw_i16'].reshape(425, 13, 13)\n"
-        "print('PROBE ' + json.dumps({'plans': [ctx.conv_plan(l.ord) for l in net.CONVS], 'ok': bool(np.array_equal(r[0], want) and np.array_equal(r[-1], want))}))\n")
+        "print('PROBE ' + json.dumps({'plans': [ctx.conv_plan(l.ord) for l in net.CONVS], 'source': ctx.plan_source(), 'ok': bool(np.array_equal(r[0], want) and np.array_equal(r[-1], want))}))\n")
     env = dict(os.environ)
     for k in ("YOLO2_PLAN_FILE", "YOLO2_PLAN_WRITE", "YOLO2_AUTOTUNE"):
         env.pop(k, None)
@@ -1048,6 +1048,7 @@ def test_plan_table_gives_every_process_the_same_plan():
     listed batch identically (and without timing anything), and the result is the fixture's."""
     a, b = _plan_probe({}), _plan_probe({})
     assert a["ok"] and b["ok"]
+    assert a["source"] == b["source"] == "plan table"
     assert a["plans"] == b["plans"]
     assert len(a["plans"]) == 23 and all(p.startswith("P=") for p in a["plans"])
 
@@ -1068,13 +1069,13 @@ def test_damaged_plan_table_costs_time_not_correctness(tmp_path):
         f = tmp_path / f"{name}.txt"
         f.write_text(text)
         r = _plan_probe({"YOLO2_PLAN_FILE": str(f)})
-        assert r["ok"], name
+        assert r["ok"] and r["source"] == "autotuned in this process", name
 
 
 def test_recorded_plan_round_trips(tmp_path):
     """YOLO2_AUTOTUNE=1 + YOLO2_PLAN_WRITE record what the autotune picked; a process given that file plans exactly that."""
     f = tmp_path / "plan.txt"
     a = _plan_probe({"YOLO2_AUTOTUNE": "1", "YOLO2_PLAN_WRITE": str(f)}, batch=5)
-    assert a["ok"] and f.exists() and len(f.read_text().splitlines()) >= 23
+    assert a["ok"] and a["source"] == "autotuned in this process" and f.exists() and len(f.read_text().splitlines()) >= 23
     b = _plan_probe({"YOLO2_PLAN_FILE": str(f)}, batch=5)
-    assert b["ok"] and b["plans"] == a["plans"]
+    assert b["ok"] and b["source"] == "plan table" and b["plans"] == a["plans"]

@@ -131,6 +131,7 @@ struct yolo2_hip_ctx {
     std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV], maxabs_mb[YOLO2_N_CONV];
     std::vector<signed char> wscale_mb[YOLO2_N_CONV];   // log2 of the factor each block's packed weights currently carry (form D)
     int *mb_lists = nullptr;           // device: block index lists of all split layers
+    int plan_source = 0;               // how set_batch planned the conv launches: 1 plan table, 2 timed (autotune), 3 static defaults
     int *ks_trip = nullptr;            // device scratch of the K-split-across-workgroups kernel (triples of every split), grown on demand
     size_t ks_trip_bytes = 0;
     // Lanes: a batch is run as part-batches on internal streams (forked from / joined to the

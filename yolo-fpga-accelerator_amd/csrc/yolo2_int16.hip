@@ -1024,16 +1024,27 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
         bool known = false;
         const int rc = apply_plan_table(c, &known);
         if (rc) return rc;
-        if (known) return YOLO2_SUCCESS;
+        if (known) { c->plan_source = 1; return YOLO2_SUCCESS; }
     }
     if (!(at && at[0] == '0')) {
+        c->plan_source = 2;
         int rc = autotune(c);
         if (rc == YOLO2_SUCCESS) rc = setup_pool_fusion(c, true, true);
         if (rc == YOLO2_SUCCESS) record_plan(c);
         return rc;
     }
+    c->plan_source = 3;
     HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);
     return setup_pool_fusion(c, false, true);
+}
+
+// 1 = the committed plan table (config/plan_gfx950.txt), 2 = timed in this process (autotune), 3 = static defaults (YOLO2_AUTOTUNE=0),
+// 0 = no batch planned yet; with lanes: lane 0's.
+extern "C" int yolo2_hip_plan_source(yolo2_hip_ctx *c)
+{
+    if (!c) return 0;
+    if (c->laned && !c->lanes.empty()) return c->lanes[0]->plan_source;
+    return c->plan_source;
 }
 
 extern "C" int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *c, int layer_idx)

@@ -42,7 +42,7 @@ EXPORTS = [
     "yolo2_hip_rccl_init_rank", "yolo2_hip_rccl_finalize", "yolo2_hip_load_weights_int16_bcast", "yolo2_hip_load_weights_fp32_bcast",
     "yolo2_hip_rccl_info", "yolo2_hip_multi_rccl_info", "yolo2_hip_ctx_device", "yolo2_hip_alloc_on",
     "yolo2_hip_fp16_layer_kernel", "yolo2_hip_f16_store_check",
-    "yolo2_hip_run_images_u8_dets", "yolo2_hip_multi_run_images_u8_dets", "yolo2_hip_set_fp16_lanes", "yolo2_hip_conv_plan_string",
+    "yolo2_hip_run_images_u8_dets", "yolo2_hip_multi_run_images_u8_dets", "yolo2_hip_set_fp16_lanes", "yolo2_hip_conv_plan_string", "yolo2_hip_plan_source",
 ]
 
 
@@ -150,6 +150,7 @@ def lib():
     L.yolo2_hip_multi_run_images_u8_dets.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, i32, vp, i32, vp, C.POINTER(i32)]
     L.yolo2_hip_set_fp16_lanes.argtypes = [vp, i32]
     L.yolo2_hip_conv_plan_string.argtypes = [vp, i32, C.c_char_p, i32]
+    L.yolo2_hip_plan_source.argtypes = [vp]
     L.yolo2_hip_rccl_info.argtypes = [vp, vp]
     L.yolo2_hip_multi_rccl_info.argtypes = [vp, vp]
     L.yolo2_hip_ctx_device.argtypes = [vp]
@@ -436,6 +437,9 @@ class Yolo2Hip:
 
     def num_lanes_fp16(self) -> int:
         return int(lib().yolo2_hip_num_lanes_fp16(self._h))
+
+    def plan_source(self) -> str:
+        return {0: "none", 1: "plan table", 2: "autotuned in this process", 3: "static defaults"}[int(lib().yolo2_hip_plan_source(self._h))]
 
     def conv_plan(self, ord_: int) -> str:
         buf = C.create_string_buffer(256)
