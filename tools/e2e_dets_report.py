@@ -12,7 +12,9 @@ base = [np.clip(np.floor(f * 256.0), 0, 255).astype(np.uint8).transpose(1, 2, 0)
 model = synth.SynthModel(seed=1)
 ctx = hipdrv.Yolo2Hip(0); ctx.load_model(model); ctx.set_batch(B)
 imgs = [base[i % 16] for i in range(4096)]
+t0 = time.perf_counter()
 hipdrv.run_images_dets(ctx._h, imgs[:2 * B], B, 0.25, 0.45)      # buffers, plan, tables
+print(f"first call ({2 * B} images: staging buffers, streams, tail tables): {(time.perf_counter() - t0) * 1e3:.1f} ms")
 for n in (B, 4 * B, 16 * B, 64 * B):
     t0 = time.perf_counter()
     reps = max(1, 2048 // n)

@@ -107,6 +107,7 @@ struct PipeBufs {
     int16_t *hout[2] = {nullptr, nullptr}, *dout[2] = {nullptr, nullptr};
     hipStream_t s_in = nullptr, s_run = nullptr, s_out = nullptr;
     hipEvent_t e_in[2] = {nullptr, nullptr}, e_run[2] = {nullptr, nullptr}, e_out[2] = {nullptr, nullptr};
+    hipEvent_t e_lane[2][8] = {};      // images -> detections entry: lane i has finished its part of the chunk in buffer set b (created on demand)
     // the tail as a pipeline stage (yolo2_hip_run_images_u8_dets): per buffer set its device buffers and pinned host mirrors
     int post_batch = 0, post_cap = 0;
     Y2PostBufs post[2];

@@ -207,6 +207,7 @@ static void pipe_free(PipeBufs &p)
         if (p.e_in[k]) (void)hipEventDestroy(p.e_in[k]);
         if (p.e_run[k]) (void)hipEventDestroy(p.e_run[k]);
         if (p.e_out[k]) (void)hipEventDestroy(p.e_out[k]);
+        for (hipEvent_t &e : p.e_lane[k]) if (e) (void)hipEventDestroy(e);
     }
     if (p.s_in) (void)hipStreamDestroy(p.s_in);
     if (p.s_run) (void)hipStreamDestroy(p.s_run);
@@ -214,9 +215,12 @@ static void pipe_free(PipeBufs &p)
     p = PipeBufs();
 }
 
-static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch)
+// need_hout: the pinned mirror of the region tensor (the entries that return region tensors; the images -> detections entry
+// downloads records instead and skips these 2 x 9 MB of pinned memory, which cost ~10 ms each to allocate)
+static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch, bool need_hout = true)
 {
-    if (p.s_in && p.host_in >= host_in && p.dev_in >= dev_in && p.batch >= batch) return YOLO2_SUCCESS;
+    if (p.s_in && p.host_in >= host_in && p.dev_in >= dev_in && p.batch >= batch && (!need_hout || p.hout[0])) return YOLO2_SUCCESS;
+    need_hout = need_hout || p.hout[0] != nullptr;
     host_in = std::max(host_in, p.host_in);
     dev_in = std::max(dev_in, p.dev_in);
     batch = std::max(batch, p.batch);
@@ -225,7 +229,7 @@ static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch)
     bool ok = true;
     for (int k = 0; k < 2 && ok; ++k) {
         ok = hipHostMalloc((void **)&p.hin[k], host_in, hipHostMallocDefault) == hipSuccess &&
-             hipHostMalloc((void **)&p.hout[k], rbytes, hipHostMallocDefault) == hipSuccess &&
+             (!need_hout || hipHostMalloc((void **)&p.hout[k], rbytes, hipHostMallocDefault) == hipSuccess) &&
              (dev_in == 0 || hipMalloc((void **)&p.dbytes[k], dev_in) == hipSuccess) &&
              hipMalloc((void **)&p.din[k], fbytes) == hipSuccess && hipMalloc((void **)&p.dout[k], rbytes) == hipSuccess &&
              hipEventCreateWithFlags(&p.e_in[k], hipEventDisableTiming) == hipSuccess &&
@@ -538,7 +542,7 @@ extern "C" int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *c, const uint8_t *con
         const int rc = yolo2_hip_set_batch(c, batch);
         if (rc) return rc;
     }
-    int rc = pipe_ensure(c->pipe, cap_bytes, cap_bytes, batch);
+    int rc = pipe_ensure(c->pipe, cap_bytes, cap_bytes, batch, false);
     if (rc == YOLO2_SUCCESS) rc = pipe_ensure_post(c, batch, cap);
     if (rc) return rc;
     PipeBufs &P = c->pipe;
@@ -585,12 +589,35 @@ extern "C" int yolo2_hip_run_images_u8_dets(yolo2_hip_ctx *c, const uint8_t *con
         hipLaunchKernelGGL(k_letterbox_u8_batch, dim3(blocks_for((long)YOLO2_FRAME_ELEMS, 256), batch), dim3(256), 0, P.s_run, P.dbytes[b], P.din[b],
                            (int)YOLO2_FRAME_ELEMS);
         Y2_TRY(hipGetLastError(), YOLO2_ERROR);
-        rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)P.din[b], batch, (uint64_t)(uintptr_t)P.dout[b], &q, P.s_run);
+        // The network.  A chunk's lanes are NOT joined back into one stream here: consecutive chunks are independent, every lane
+        // owns its activations and its stream keeps its chunks in order, so lane i starts chunk k + 1 the moment it has finished
+        // chunk k (and the chunk's letterbox is done) instead of waiting for the slowest lane - the fork / join per 64 frames and the
+        // lanes' end spread (0.3 - 0.7 ms of a 20 ms step in the bench loop) do not exist in a stream of chunks.  Only the tail,
+        // which needs the whole region tensor, waits for all of them, on the download stream.
+        bool own_streams = c->laned && (int)c->lanes.size() <= 8;
+        if (own_streams) for (yolo2_hip_ctx *l : c->lanes) own_streams = own_streams && l->lane_stream;
+        Y2_TRY(hipEventRecord(P.e_run[b], P.s_run), YOLO2_ERROR);            // (here: the letterboxed frames are ready)
+        if (own_streams) {
+            for (size_t i = 0; i < c->lanes.size() && rc == YOLO2_SUCCESS; ++i) {
+                yolo2_hip_ctx *l = c->lanes[i];
+                const uint64_t first = (uint64_t)c->lane_first[i];
+                if (!P.e_lane[b][i]) Y2_TRY(hipEventCreateWithFlags(&P.e_lane[b][i], hipEventDisableTiming), YOLO2_ERROR);
+                Y2_TRY(hipStreamWaitEvent(l->lane_stream, P.e_run[b], 0), YOLO2_ERROR);
+                rc = yolo2_hip_run_batch_int16(l, (uint64_t)(uintptr_t)(P.din[b] + first * YOLO2_FRAME_ELEMS), l->batch,
+                                               (uint64_t)(uintptr_t)(P.dout[b] + first * YOLO2_REGION_ELEMS), &q, l->lane_stream);
+                if (rc) break;
+                Y2_TRY(hipEventRecord(P.e_lane[b][i], l->lane_stream), YOLO2_ERROR);
+                Y2_TRY(hipStreamWaitEvent(P.s_out, P.e_lane[b][i], 0), YOLO2_ERROR);
+            }
+        } else {
+            rc = yolo2_hip_run_batch_int16(c, (uint64_t)(uintptr_t)P.din[b], batch, (uint64_t)(uintptr_t)P.dout[b], &q, P.s_run);
+            if (rc) break;
+            Y2_TRY(hipEventRecord(P.e_run[b], P.s_run), YOLO2_ERROR);
+            Y2_TRY(hipStreamWaitEvent(P.s_out, P.e_run[b], 0), YOLO2_ERROR);
+        }
         if (rc) break;
-        Y2_TRY(hipEventRecord(P.e_run[b], P.s_run), YOLO2_ERROR);
         // the step after the path, on the device that produced the tensor, straight from HBM - on the download stream, so that the
-        // next chunk's letterbox and network follow this chunk's network at once (the tail is 64 workgroups for 0.7 ms: latency, not work)
-        Y2_TRY(hipStreamWaitEvent(P.s_out, P.e_run[b], 0), YOLO2_ERROR);
+        // next chunk's letterbox and network need not wait for it (the tail is 64 workgroups for 0.7 ms: latency, not work)
         rc = y2_post_enqueue_int16(c->device, P.dout[b], batch, q, thresh, nms, cap, best_only, &P.post[b], P.s_out);
         if (rc) break;
         Y2_TRY(hipMemcpyAsync(P.hcounts[b], P.post[b].counts, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, P.s_out), YOLO2_DMA_ERROR);

@@ -513,6 +513,9 @@ void run_stream(AppConfig cfg)
         std::unique_ptr<Chunk> ck;
         std::vector<int16_t> region;
         std::vector<yolo2_hip_det> recs;
+        // while the reader decodes its first chunk: plan the batch (activation tensors, lanes) on every device
+        for (int i = 0; i < yolo2_hip_multi_num_devices(m); ++i)
+            if (yolo2_hip_set_batch(yolo2_hip_multi_ctx(m, i), cfg.batch) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
         while (to_run.pop(ck)) {
             const int n = (int)ck->frames.size();
             std::vector<const uint8_t *> ptrs((size_t)n);
