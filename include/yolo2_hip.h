@@ -281,7 +281,7 @@ int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x
 int yolo2_hip_conv_plan_string(yolo2_hip_ctx *ctx, int conv_ordinal, char *buf, int cap);
 /* Where the current batch's conv plan came from: 1 = the plan table shipped next to the library (config/plan_gfx950.txt: the same
  * kernels in every process), 2 = timed in this process (a batch or a model the table does not hold, or YOLO2_AUTOTUNE=1),
- * 3 = static defaults (YOLO2_AUTOTUNE=0), 0 = no batch planned yet. */
+ * 3 = static defaults (YOLO2_AUTOTUNE=0), 4 = forced by a test hook (YOLO2_FORCE_P), 0 = no batch planned yet. */
 int yolo2_hip_plan_source(yolo2_hip_ctx *ctx);
 
 /* fp32 whole network in the reference's own arithmetic (what yolov2_hls_ps does at Precision::FP32,

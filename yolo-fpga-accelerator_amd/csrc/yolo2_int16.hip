@@ -1010,6 +1010,7 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
             for (auto &e : c->extra[i])
                 plan_conv(e, tin.g, tout.g.cg_stride, kLead + (i == 24 ? (long)64 * tout.g.cg_stride : 0), (kNet[i].n + 3) / 4, atoi(fp));
         }
+        c->plan_source = 4;
         HIP_TRY(hipDeviceSynchronize(), YOLO2_ERROR);   // (the tensors' zero fills ran on the null stream)
         return setup_pool_fusion(c, false, false);      // fixed tile shapes: fusion only on request (YOLO2_POOLFUSE=1)
     }
@@ -1039,7 +1040,7 @@ static int set_batch_single(yolo2_hip_ctx *c, int batch)
 }
 
 // 1 = the committed plan table (config/plan_gfx950.txt), 2 = timed in this process (autotune), 3 = static defaults (YOLO2_AUTOTUNE=0),
-// 0 = no batch planned yet; with lanes: lane 0's.
+// 4 = forced by a test hook (YOLO2_FORCE_P), 0 = no batch planned yet; with lanes: lane 0's.
 extern "C" int yolo2_hip_plan_source(yolo2_hip_ctx *c)
 {
     if (!c) return 0;

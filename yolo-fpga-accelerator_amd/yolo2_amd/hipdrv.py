@@ -439,7 +439,7 @@ class Yolo2Hip:
         return int(lib().yolo2_hip_num_lanes_fp16(self._h))
 
     def plan_source(self) -> str:
-        return {0: "none", 1: "plan table", 2: "autotuned in this process", 3: "static defaults"}[int(lib().yolo2_hip_plan_source(self._h))]
+        return {0: "none", 1: "plan table", 2: "autotuned in this process", 3: "static defaults", 4: "forced by a test hook"}[int(lib().yolo2_hip_plan_source(self._h))]
 
     def conv_plan(self, ord_: int) -> str:
         buf = C.create_string_buffer(256)
