@@ -258,9 +258,12 @@ int y2_lane_stream_create(hipStream_t *s)
         HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking), YOLO2_ERROR);
         return YOLO2_SUCCESS;
     }
-    int least = 0, greatest = 0;
-    HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest), YOLO2_ERROR);   // numerically lower = higher priority
-    HIP_TRY(hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest), YOLO2_ERROR);
+    int least = 0, greatest = 0;   // numerically lower = higher priority
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest < least &&
+        hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess)
+        return YOLO2_SUCCESS;
+    (void)hipGetLastError();       // a runtime without stream priorities: an ordinary stream (correct, possibly sharing a hardware queue)
+    HIP_TRY(hipStreamCreateWithFlags(s, hipStreamNonBlocking), YOLO2_ERROR);
     return YOLO2_SUCCESS;
 }
 
