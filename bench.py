@@ -24,11 +24,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "yolo-fpga-accelerator_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+# torch (device memory, streams, torch.distributed) and the ctypes binding are imported by load_runtime(), i.e. only in a
+# process that is going to run a rank: the launcher form of `python bench.py --gpus N` (spawn_ranks) starts N fresh children
+# and must neither pay for the import nor come anywhere near the GPU itself.
+torch = dist = ydist = hipdrv = net = synth = None
 
-from yolo2_amd import dist as ydist  # noqa: E402
-from yolo2_amd import hipdrv, net, synth  # noqa: E402
+
+def load_runtime():
+    global torch, dist, ydist, hipdrv, net, synth
+    import torch as _torch
+    import torch.distributed as _dist
+    from yolo2_amd import dist as _ydist
+    from yolo2_amd import hipdrv as _hipdrv, net as _net, synth as _synth
+    torch, dist, ydist, hipdrv, net, synth = _torch, _dist, _ydist, _hipdrv, _net, _synth
+
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # VALU issue roofline: 256 CU x 4 SIMD issue one wave64 instruction per 2 or 4 cycles depending on
@@ -453,6 +462,65 @@ def sub_fp32_exact(model, dev, B=32, steps=3, warmup=1):
                               "note": "18 issue cycles per (4 channels x tap x 64 outputs): 4 v_mul_f32 + 5 v_add_f32 at 2 cycles each"}}
 
 
+def sub_c5_b256(ctx, rank, world, dev, steps=5, warmup=2):
+    """configs[4] (C5) at its own size, collective over all ranks: 2048 frames over 8 GPUs = a 256-frame shard per GPU (at N ranks:
+    N x 256), same protocol as the headline (barrier + synchronize on both sides, max over ranks).  Every rank calls this.
+    Frames: rank r holds global frames [256 r, 256 r + 32) tiled to its 256 (the frame generator is CPU-bound, 23 ms each)."""
+    B = 256
+    err = None
+    try:
+        ctx.set_batch(B)
+        lo, _ = ydist.shard_range(B * world, rank, world)
+        base = synth.frames(7, 32, first=lo)
+        frames = torch.from_numpy(base).to(dev).repeat(B // 32, 1, 1, 1).contiguous()
+        region = torch.empty((B, 425, 13, 13), dtype=torch.int16, device=dev)
+    except Exception as e:      # noqa: BLE001 - a rank that cannot hold the 256-frame shard must not leave the others in a barrier
+        err = e
+    if not ydist.all_ok(err is None, dev):
+        return {"error": f"rank {rank}: {err}" if err else "another rank could not set up its 256-frame shard"} if rank == 0 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist.is_initialized():
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        ctx.run_batch_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.run_batch_ptr(frames.data_ptr(), B, region.data_ptr(), stream.cuda_stream)
+    fence()
+    dt_rank = time.perf_counter() - t0
+    dt = dt_rank
+    rccl, per_rank = rccl_record(ctx, B, steps, dt_rank, dev)
+    if dist.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    same = bool(torch.equal(region[0], region[B - 32]))          # the same frame at two batch positions (two different lanes)
+    if rank != 0:
+        return None
+    counts = ctx.layer_path_counts()
+    cyc = 0.0
+    for l in net.CONVS:
+        cnt = counts[l.ord]
+        mean_c = sum(cnt[k] * (CYCLES_PER_STEP[k] or 40) for k in range(5)) / sum(cnt)
+        cyc += l.size * l.size * ((l.c + 3) // 4) * l.n * l.out_h * l.out_w * B / 64 * mean_c
+    used = cyc / (dt / steps) / 1e12
+    rec = {"metric": "YOLOv2 INT16 416x416 frames/sec", "value": world * B * steps / dt, "unit": "frames/s", "n_gpus": world,
+           "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3, "scaling": "weak", "dtype": "int16",
+           "config": {"workload": f"C5 shard size: YOLOv2 INT16 416x416 batch={B} per GPU ({B * world} frames over {world} GPU(s); "
+                                  "BASELINE.json configs[4] = 2048 over 8)", "batch_per_gpu": B, "global_batch": B * world,
+                      "lanes": ctx.num_lanes(), "conv_plan_source": ctx.plan_source()},
+           "valu_roofline_frac": used / VALU_PEAK_TCYCLES, "same_frame_same_result_across_lanes": same}
+    if rccl is not None:
+        rec["rccl_nranks"], rec["per_rank"] = rccl["nranks"], per_rank
+    return rec
+
+
 def sub_latency_b1(ctx, frames, region, dev, n=30):
     """configs[1] under the driver's clock: one frame per call, one host sync per frame (device-resident in and out)."""
     stream = torch.cuda.current_stream(dev)
@@ -480,6 +548,112 @@ def sub_latency_b1(ctx, frames, region, dev, n=30):
                     "per layer as the plan table / set_batch's timing says"}
 
 
+RANK_EXIT_GRACE_S = float(os.environ.get("YOLO2_BENCH_RANK_GRACE_S", "10"))
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv, out_fd):
+    """`python bench.py --gpus N` without a launcher around it: start N FRESH interpreter processes of this same file, one per
+    GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set as torch.distributed.run would set them, relay
+    rank 0's single JSON line to our stdout, and return the job's exit code: 0 only if every rank returned 0.  When a rank fails,
+    the others get RANK_EXIT_GRACE_S to leave by themselves (bench.py's phases end collectively: ydist.all_ok) and are then
+    terminated, so a dead rank never leaves a hung job behind.  This process has not imported torch and never touches the GPU."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port, YOLO2_BENCH_LAUNCHER="bench.py")
+        # rank 0's stdout is the record; the other ranks print nothing there, but if a library does it goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else 2, close_fds=True))
+    print(f"bench.py[launcher]: started {n} ranks (pids {[p.pid for p in procs]}), rendezvous 127.0.0.1:{port}", file=sys.stderr, flush=True)
+    import threading
+    got = []
+    reader = threading.Thread(target=lambda: got.append(procs[0].stdout.read()), daemon=True)   # never blocks the watchdog loop below
+    reader.start()
+    codes = [None] * n
+    deadline = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes) and deadline is None:
+            deadline = time.monotonic() + RANK_EXIT_GRACE_S
+        if deadline is not None and time.monotonic() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    print(f"bench.py[launcher]: rank {i} still running {RANK_EXIT_GRACE_S:.0f} s after another rank failed: terminating it",
+                          file=sys.stderr, flush=True)
+                    p.terminate()
+                    try:
+                        codes[i] = p.wait(5)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+        time.sleep(0.05)
+    reader.join(5)
+    line = b""
+    for ln in (got[0] if got else b"").splitlines():
+        if ln.strip().startswith(b"{"):
+            line = ln.strip()
+    bad = [(i, c) for i, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py[launcher]: ranks failed (rank, exit code): {bad}", file=sys.stderr, flush=True)
+        return next(c for _, c in bad if c > 0) if any(c > 0 for _, c in bad) else 1
+    if not line:
+        print("bench.py[launcher]: every rank returned 0 but rank 0 printed no record", file=sys.stderr, flush=True)
+        return 1
+    os.write(out_fd, line + b"\n")
+    return 0
+
+
+def dry_rank(rank, local_rank, world, emit):
+    """--dry-launch: what a rank does in the launcher's rehearsal (CPU test, no GPU, no torch): the ranks meet over a real
+    world-size-N gloo-free rendezvous of their own - a TCP socket on MASTER_ADDR:MASTER_PORT that rank 0 listens on - so the
+    test proves that every rank got the SAME address and port, a distinct RANK / LOCAL_RANK and the right WORLD_SIZE; rank 0
+    prints the one record.  YOLO2_BENCH_DRY_FAIL_RANK=r makes rank r exit 3 after the rendezvous (exit-code propagation), with
+    YOLO2_BENCH_DRY_FAIL_EARLY=1 before it (the launcher must end the ranks left waiting)."""
+    import socket
+    addr, port = os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"])
+    mine = {"rank": rank, "local_rank": local_rank, "world_size": world, "master": f"{addr}:{port}", "pid": os.getpid(),
+            "launcher": os.environ.get("YOLO2_BENCH_LAUNCHER", "external")}
+    fail = int(os.environ.get("YOLO2_BENCH_DRY_FAIL_RANK", "-1"))
+    if rank == fail and os.environ.get("YOLO2_BENCH_DRY_FAIL_EARLY") == "1":
+        sys.exit(3)          # dies before the rendezvous: the others would wait for it - the launcher's watchdog ends them
+    if rank == 0:
+        rows = [mine]
+        with socket.socket() as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(60)
+            for _ in range(world - 1):
+                c, _a = srv.accept()
+                with c:
+                    rows.append(json.loads(c.makefile().readline()))
+        rows.sort(key=lambda r: r["rank"])
+        emit({"dry_launch": True, "n_gpus": world, "ranks": rows})
+    else:
+        t_end = time.monotonic() + 60
+        while True:
+            try:
+                with socket.create_connection((addr, port), timeout=5) as c:
+                    c.sendall((json.dumps(mine) + "\n").encode())
+                break
+            except OSError:
+                if time.monotonic() > t_end:
+                    raise
+                time.sleep(0.05)
+    sys.exit(3 if rank == fail else 0)
+
+
 def main():
     # stdout carries exactly ONE line, the JSON record.  Libraries chat on fd 1 (RCCL prints a version banner there when a
     # communicator is created under NCCL_DEBUG=VERSION/WARN), so everything written to fd 1 during the run is sent to stderr
@@ -501,19 +675,35 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub-records", action="store_true",
                     help="skip the latency_b1 (configs[1]) and fp16_b256 (configs[3]) sub-records of the default line")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="rehearse the --gpus N launcher without a GPU: the ranks only report the environment they were started with")
     ap.add_argument("--precision", choices=["int16", "fp16"], default="int16",
                     help="int16 = the headline bit-exact path; fp16 = MFMA implicit-GEMM path (configs[3], use --batch 256)")
     args = ap.parse_args()
 
+    # ---- which process is this?  (a) a rank: RANK / LOCAL_RANK / WORLD_SIZE are in the environment (torch.distributed.run, or
+    # the launcher below);  (b) `python bench.py --gpus N` typed plainly with N > 1: the launcher - it starts N fresh rank
+    # processes and relays rank 0's line;  (c) one GPU, no launcher needed.  Decided before torch is imported: the launcher never
+    # touches the GPU (a process that has initialised HIP must not fork or exec its ranks).
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], out_fd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher (torch.distributed.run or bench.py itself) "
+                  f"must start exactly --gpus ranks", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.dry_launch:       # a rank of the launcher's rehearsal: report what it was given, touch nothing
+        return dry_rank(rank, local_rank, world, emit)
+    load_runtime()
+    # device_count() does not initialise the GPU on this image; every rank sees the same number, so every rank leaves here
+    # together and nobody waits in a rendezvous for a rank that has no device
+    if torch.cuda.device_count() < max(1, world) or not torch.cuda.is_available():
+        print(f"bench.py[rank {rank}]: --gpus {world} needs {world} GPU(s), this node shows {torch.cuda.device_count()}"
+              " (the HIP path has no CPU fallback)", file=sys.stderr, flush=True)
+        sys.exit(4)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # YOLO2_BENCH_FORCE_DIST=1 initialises RCCL even for one rank (rehearses the multi-GPU code path on a 1-GPU box)
@@ -653,9 +843,15 @@ def main():
             idx = [0, B - 1]    # first frame of the first lane, last frame of the last
             result["cpu_baseline"] = cpu_baseline(model, [frames[i].cpu().numpy() for i in idx],
                                                   [region[i].cpu().numpy() for i in idx])
+    r0 = region[0].clone()
+    if not args.no_sub_records:
+        # configs[4] at its own shard size (256 frames per GPU), on EVERY rank count incl. 1: a collective sub-record
+        c5 = sub_c5_b256(ctx, rank, world, dev)
+        if rank == 0:
+            result["c5_b256_per_gpu"] = c5
+    if rank == 0:
         if world == 1 and not args.no_sub_records:
             # configs[1] and configs[3] under the same clock as the headline: ~10 s together
-            r0 = region[0].clone()
             result["latency_b1"] = sub_latency_b1(ctx, frames, region, dev)
             result["latency_b1"]["matches_batched_result_bit_exact"] = bool(torch.equal(region[0], r0))
             ctx.close()

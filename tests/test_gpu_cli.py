@@ -222,3 +222,43 @@ def test_cli_dog_jpg_end_to_end_reproduces_c1_fixture(tmp_path):
     r = _run(["--weights", str(tmp_path / "weights"), "--input-list", str(lst), "--batch", "2", "--thresh", "0.05", "--jsonl", str(tmp_path / "o.jsonl")], tmp_path)
     recs = [json.loads(l) for l in open(tmp_path / "o.jsonl")]
     assert [(x["width"], x["height"]) for x in recs] == [(768, 576), (216, 216), (323, 240)]
+
+
+def test_cli_streaming_skips_an_undecodable_file_and_keeps_the_order_over_two_device_lanes(tmp_path):
+    """Round 4: a chunk belongs to ONE device lane (devices pop chunks as they become free; the writer restores the stream order),
+    and one undecodable file no longer ends the stream: it is logged and skipped, --strict restores the old behaviour.
+    11 small images + one damaged file, batch 2, one batch per chunk, two contexts on the one GPU: the records come out in list
+    order with consecutive inference indices, the damaged frame keeps its frame_index slot, detections equal the one-lane run."""
+    import json
+    import re
+    model = synth.SynthModel(seed=1, obj_bias=2.0)
+    wdir = tmp_path / "weights"
+    model.write_files(str(wdir), fp32=False)
+    rng = np.random.default_rng(21)
+    paths = []
+    for k in range(11):
+        h, w = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+        p = tmp_path / f"im_{k:02d}.ppm"
+        _write_ppm(p, rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
+        paths.append(str(p))
+    bad = tmp_path / "broken.png"
+    bad.write_bytes(b"\x89PNG\r\n\x1a\n" + b"\x00" * 40)
+    listed = paths[:5] + [str(bad)] + paths[5:]
+    (tmp_path / "list.txt").write_text("\n".join(listed) + "\n")
+    common = ["--weights", str(wdir), "--thresh", "0.1", "--input-list", str(tmp_path / "list.txt"), "--batch", "2", "--chunk-batches", "1"]
+    outs = {}
+    for tag, extra in (("two", ["--devices", "0,0"]), ("one", [])):
+        out = tmp_path / f"{tag}.jsonl"
+        r = _run(common + extra + ["--jsonl", str(out)], tmp_path)
+        recs = [json.loads(l) for l in out.read_text().splitlines()]
+        assert [x["source"] for x in recs] == paths, tag
+        assert [x["inference_index"] for x in recs] == list(range(1, 12))
+        assert [x["frame_index"] for x in recs] == [1, 2, 3, 4, 5, 7, 8, 9, 10, 11, 12]       # frame 6 is the damaged file
+        assert "Frame 6 skipped" in r.stdout and "1 frame(s) skipped" in r.stdout and "broken.png" in r.stderr
+        times = re.findall(r"Frame (\d+) \(infer (\d+)\) inference time", r.stdout)
+        assert [int(b) for _, b in times] == list(range(1, 12))
+        outs[tag] = [x["detections"] for x in recs]
+    assert outs["two"] == outs["one"]
+    r = subprocess.run([CLI, "--cfg", os.path.join(PKG, "config", "yolov2.cfg"), "--names", os.path.join(PKG, "config", "coco.names")] + common + ["--strict"],
+                       capture_output=True, text=True, cwd=str(tmp_path), env=dict(os.environ, YOLO2_NO_DUMP="1"))
+    assert r.returncode == 1 and "broken.png" in r.stderr

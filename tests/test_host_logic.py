@@ -301,3 +301,81 @@ def test_committed_plan_table_is_well_formed():
         assert all((B, L, 0) in rows for L in convs), B
         for (b, L, S) in rows:
             assert b != B or S == 0 or (b, L, S - 1) in rows      # launches of a layer are numbered without holes
+
+
+# ------------------------------------------------------------------ round 4: bench.py starts its own ranks
+
+def _run_bench(args, env=None, timeout=120):
+    import subprocess
+    e = dict(os.environ, **(env or {}))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_one_fresh_rank_per_gpu_dry():
+    """`python bench.py --gpus 2` typed plainly (no torch.distributed.run, no WORLD_SIZE) must start its ranks itself
+    (it exited 2).  --dry-launch rehearses exactly that launcher without a GPU: two fresh processes, distinct RANK /
+    LOCAL_RANK, one WORLD_SIZE, one rendezvous address that rank 1 really reaches rank 0 on; ONE JSON line on stdout."""
+    import json
+    p = _run_bench(["--gpus", "2", "--dry-launch"])
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["dry_launch"] and rec["n_gpus"] == 2
+    rows = rec["ranks"]
+    assert [r["rank"] for r in rows] == [0, 1] and [r["local_rank"] for r in rows] == [0, 1]
+    assert all(r["world_size"] == 2 and r["launcher"] == "bench.py" for r in rows)
+    assert rows[0]["master"] == rows[1]["master"] and rows[0]["master"].startswith("127.0.0.1:")
+    assert len({r["pid"] for r in rows} | {os.getpid()}) == 3          # fresh processes, not threads of the launcher
+
+
+@pytest.mark.parametrize("early", ["0", "1"])
+def test_bench_launcher_propagates_a_failed_rank(early):
+    """A rank that exits non-zero makes the launcher exit non-zero with that code, prints no record, and - when the rank died
+    before the rendezvous, so that rank 0 waits for it - ends the waiting ranks after the grace period instead of hanging."""
+    p = _run_bench(["--gpus", "2", "--dry-launch"], {"YOLO2_BENCH_DRY_FAIL_RANK": "1", "YOLO2_BENCH_DRY_FAIL_EARLY": early,
+                                                      "YOLO2_BENCH_RANK_GRACE_S": "1"}, timeout=60)
+    assert p.returncode == 3, (p.returncode, p.stderr)
+    assert p.stdout.strip() == ""
+    assert "ranks failed" in p.stderr
+    if early == "1":
+        assert "terminating it" in p.stderr
+
+
+def test_bench_without_enough_gpus_says_so_from_the_ranks():
+    """On a node with fewer GPUs than --gpus every child rank says 'needs N GPU(s)' and leaves with code 4 at once (before any
+    rendezvous), and the launcher returns that code: not exit 2 from argument handling, not a hang."""
+    L = hipdrv.lib()
+    have = L.yolo2_hip_device_count()
+    n = have + 2
+    p = _run_bench(["--gpus", str(n), "--steps", "1", "--warmup", "0"], timeout=300)
+    assert p.returncode == 4, (p.returncode, p.stderr[-2000:])
+    assert p.stderr.count(f"needs {n} GPU(s)") == n
+    assert p.stdout.strip() == ""
+
+
+def test_bench_rank_environment_without_launcher_is_still_accepted():
+    """The driver's form - torch.distributed.run sets RANK / WORLD_SIZE and runs bench.py as a rank - keeps working: with
+    WORLD_SIZE present bench.py is a rank, never a launcher (dry: the ranks only report)."""
+    import json
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ps = []
+    for r in range(2):
+        e = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        e.pop("YOLO2_BENCH_LAUNCHER", None)
+        ps.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=e,
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=90) for p in ps]
+    assert [p.returncode for p in ps] == [0, 0], outs
+    rec = json.loads(outs[0][0].strip())
+    assert [r["launcher"] for r in rec["ranks"]] == ["external", "external"] and outs[1][0].strip() == ""
+    # a WORLD_SIZE that contradicts --gpus is still an argument error (exit 2)
+    e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=e, capture_output=True, text=True)
+    assert p.returncode == 2 and "must start exactly" in p.stderr
