@@ -821,7 +821,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"frames sharded x{world}, weights broadcast once",
                        "conv_paths": paths, "conv_path_block_counts": ctx.layer_path_counts(),
                        "lanes": lanes, "frames_per_launch": Bl, "conv_pool_fused_layers": fused,
-                       "conv_plans": {l.idx: ctx.conv_plan(l.ord) for l in net.CONVS}, "conv_plan_source": ctx.plan_source()},
+                       "conv_plans": {l.idx: ctx.conv_plan(l.ord) for l in net.CONVS}, "conv_plan_source": ctx.plan_source(),
+                       "options": ctx.options()},
             "roofline": {"bound": "hbm", "kernel": kname, "launches_per_step": g["launches"], "layers": g["layers"],
                          "avg_launch_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,

@@ -281,8 +281,47 @@ int yolo2_hip_conv_launch_info(yolo2_hip_ctx *ctx, int conv_ordinal, int *grid_x
 int yolo2_hip_conv_plan_string(yolo2_hip_ctx *ctx, int conv_ordinal, char *buf, int cap);
 /* Where the current batch's conv plan came from: 1 = the plan table shipped next to the library (config/plan_gfx950.txt: the same
  * kernels in every process), 2 = timed in this process (a batch or a model the table does not hold, or YOLO2_AUTOTUNE=1),
- * 3 = static defaults (YOLO2_AUTOTUNE=0), 4 = forced by a test hook (YOLO2_FORCE_P), 0 = no batch planned yet. */
+ * 3 = static defaults (autotune=0), 4 = forced by a test hook (force_p), 5 = the weight-side cache bound with
+ * yolo2_hip_set_plan_cache (the same kernels in every process for THIS weight set), 0 = no batch planned yet. */
 int yolo2_hip_plan_source(yolo2_hip_ctx *ctx);
+
+/* ------------------------------------------------------- options: one parsed-once set per context
+ *
+ * Every switch that steers kernel selection, lanes or planning is a named option of the context.  The set is filled from the
+ * environment (YOLO2_<NAME>, upper case) ONCE, inside yolo2_hip_create; afterwards only this call changes it (it takes effect at the
+ * next weight load / yolo2_hip_set_batch).  Nothing on a planning or launch path reads the environment.  Names (README.md has the
+ * list with meanings): planning - autotune, plan_file, plan_write, lanes, no_lanes, lane_split, no_plan_cache, verbose; kernel-family
+ * A/B switches - splitk, poolfuse, no_poolfuse, no_hiacc, no_ks, no_w16, no_grp, no_xcd_remap, splitk_no_pack, f16_*; test hooks
+ * that force one shape everywhere - force_path, force_p, force_w16, force_hiacc, force_ks, f32_p.  value NULL or "" restores the
+ * default; flags are on for any value but "0".  YOLO2_ERROR for an unknown name or a value out of range.  ctx = NULL addresses the
+ * process-wide set the context-less driver tier (yolo2_execute_conv_layer ...) plans with (filled from the environment at first use).
+ * (The reference's own variables - YOLO2_VERBOSE, YOLO2_NO_DUMP, YOLO2_DUMP_REGION*: linux_app/include/yolo2_log.h:27-36,
+ * hls/models/yolov2/yolo2_model.cpp:427-438 - keep their names.) */
+int yolo2_hip_set_option(yolo2_hip_ctx *ctx, const char *name, const char *value);
+/* The options that differ from their defaults as "name=value name=value" ("" if none): what bench.py discloses with its record. */
+int yolo2_hip_options_string(yolo2_hip_ctx *ctx, char *buf, int cap);
+
+/* ------------------------------------------------------- the weight-side plan cache
+ *
+ * The reference prepares a weight set once, offline (src/models/yolov2/yolov2_weight_gen.cpp:34-68 writes weights_reorg*.bin;
+ * the loader hls/models/yolov2/yolo2_model.cpp:158-227 only reads).  The analogue here: a small text file beside the weight set,
+ * `<weights_reorg_int16.bin>.y2plan`, that this library writes the first time it has timed a batch for that weight set and reads at
+ * every later load: a hash of the blobs and Q tables, the per-block bounds behind the arithmetic-form proofs (k_weight_bound* is
+ * then skipped), the forms / scale shifts derived from them (re-derived and compared), and the conv plan of every timed batch as
+ * plan_gfx950.txt lines (the autotune is then skipped and every process runs the same kernels).  A missing, stale (other hash),
+ * damaged (checksum) or unwritable file costs time, never correctness.  weights_reorg_int16.bin stays the interchange format.
+ * set_plan_cache binds the file to the context (NULL / "" unbinds) and takes effect at the next yolo2_hip_load_weights_int16*. */
+int yolo2_hip_set_plan_cache(yolo2_hip_ctx *ctx, const char *path);
+/* hash of the loaded weight set, whether the file's bounds were used at the last load, plan lines / batches held */
+int yolo2_hip_plan_cache_info(yolo2_hip_ctx *ctx, uint64_t *weights_hash, int *bounds_from_file, int *n_lines, int *n_batches);
+/* Test hook (no GPU): would the file be accepted for a weight set with this hash?  YOLO2_ERROR + the reason otherwise. */
+int yolo2_hip_plan_cache_check(const char *path, uint64_t weights_hash, int *n_lines);
+
+/* The K-split-over-workgroups kernel (k_conv_i16_ks, single frames) stores `splits` clamp-affine triples of 24 bytes per output item
+ * (4 channels) and pixel into the context's scratch.  The rule every such plan passes in plan_conv and again at launch, on plain
+ * numbers (no GPU): splits in {2,4,8,16} and splits x cg_out x npix x 24 <= cap_bytes; cap_bytes = 0 (a context without scratch:
+ * batch > 4) refuses every split.  Round 3's GPU memory fault was this rule violated. */
+int yolo2_hip_i16_plan_check(int splits, int cg_out, int npix, size_t cap_bytes);
 
 /* fp32 whole network in the reference's own arithmetic (what yolov2_hls_ps does at Precision::FP32,
  * hls/models/yolov2/yolo2_model.cpp:229-449: compute() fp32 branch core_compute.cpp:121-172 in its

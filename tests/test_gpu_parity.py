@@ -35,13 +35,15 @@ def driver():
 
 
 @pytest.fixture
-def force_path(monkeypatch):
+def force_path():
+    """The arithmetic form the per-layer driver calls must use (test hook `force_path` of the driver tier's process-wide option
+    set: yolo2_hip_set_option(NULL, ...); contexts take theirs from the environment at creation)."""
+    L = hipdrv.lib()
+
     def _set(v):
-        if v is None:
-            monkeypatch.delenv("YOLO2_FORCE_PATH", raising=False)
-        else:
-            monkeypatch.setenv("YOLO2_FORCE_PATH", str(v))
-    return _set
+        hipdrv.check(L.yolo2_hip_set_option(None, b"force_path", None if v is None else str(v).encode()), "yolo2_hip_set_option")
+    yield _set
+    _set(None)
 
 
 # ------------------------------------------------------------------ per-layer driver calls
@@ -843,7 +845,12 @@ def test_set_batch_leaves_lane_mode_on_a_live_context(monkeypatch):
     assert ctx.num_lanes() == 3
     ctx.set_profiling(True)
     r1, _ = ctx.run_batch_host(frames)
-    monkeypatch.setenv("YOLO2_NO_LANES", "1")
+    monkeypatch.setenv("YOLO2_NO_LANES", "1")       # the environment is read ONCE, at context creation: a live context ignores it ...
+    ctx.set_batch(64)
+    assert ctx.num_lanes() == 3
+    monkeypatch.delenv("YOLO2_NO_LANES")
+    ctx.set_option("no_lanes", 1)                   # ... and changes only through yolo2_hip_set_option
+    assert ctx.options() == "no_lanes=1"
     ctx.set_batch(64)
     assert ctx.num_lanes() == 1
     r2, _ = ctx.run_batch_host(frames)
@@ -852,7 +859,8 @@ def test_set_batch_leaves_lane_mode_on_a_live_context(monkeypatch):
     assert ctx.layer_times_ms().sum() > 0
     r3, _ = ctx.run_batch_host(frames[:1])          # profiled at batch 64, now batch 1
     assert np.array_equal(r3[0], r1[0]) and ctx.layer_times_ms().sum() > 0
-    monkeypatch.delenv("YOLO2_NO_LANES")
+    ctx.set_option("no_lanes", None)
+    assert ctx.options() == ""
     r4, _ = ctx.run_batch_host(frames)
     assert ctx.num_lanes() == 3 and np.array_equal(r4, r1)
     ctx.close()
@@ -1079,3 +1087,104 @@ def test_recorded_plan_round_trips(tmp_path):
     assert a["ok"] and a["source"] == "autotuned in this process" and f.exists() and len(f.read_text().splitlines()) >= 23
     b = _plan_probe({"YOLO2_PLAN_FILE": str(f)}, batch=5)
     assert b["ok"] and b["source"] == "plan table" and b["plans"] == a["plans"]
+
+
+# ------------------------------------------------------------------ round 4: the weight-side plan cache
+
+def test_weight_side_plan_cache_makes_a_second_model_deterministic(tmp_path):
+    """the committed plan table only fits the synthetic bench model; any other weight set silently autotuned
+    (2 s, run-to-run different picks).  A SECOND synthetic family (other seed, gain 2.5, other Q tables -> other arithmetic forms per
+    block than the bench model's) with a cache file bound: load 1 computes the bounds, times the batches and writes the file; load 2
+    (a new context, as another process would be) takes bounds and plans from the file - no k_weight_bound*, no timing - reports
+    "weight cache", runs the SAME plans and gives the same bits, which are the oracle's.  Then the file meets another weight set
+    (stale: refused, re-timed, rewritten for that set) and a flipped byte (damaged: refused) - time, never correctness."""
+    wq = [13] * 23
+    aq = [14] + [8] * 23
+    model = synth.SynthModel(seed=3, gain=2.5, weight_q=wq, act_q=aq)
+    frames = synth.frames(31, 2)
+    orclib.oracle().orc_set_threads(16)
+    want = [orclib.forward_i16(model, frames[f])[0] for f in range(2)]
+    cache = tmp_path / "weights_reorg_int16.bin.y2plan"
+
+    def run(m, expect_source, expect_bounds):
+        ctx = hipdrv.Yolo2Hip(0)
+        ctx.set_plan_cache(cache)
+        ctx.load_model(m)
+        out = {}
+        for batch in (1, 2):
+            ctx.set_batch(batch)
+            assert ctx.plan_source() == expect_source, (batch, ctx.plan_source())
+            out[batch] = ([ctx.conv_plan(o) for o in range(23)], ctx.run_batch_host(frames[:batch])[0])
+        info = ctx.plan_cache_info()
+        assert info["bounds_from_file"] == expect_bounds, info
+        counts = np.array(ctx.layer_path_counts())
+        ctx.close()
+        return out, info, counts
+
+    first, info1, counts = run(model, "autotuned in this process", False)
+    std = hipdrv.Yolo2Hip(0)
+    std.load_model(synth.SynthModel(seed=1))
+    assert not np.array_equal(np.array(std.layer_path_counts()), counts), "the second family must differ in arithmetic forms from the bench model"
+    std.close()
+    assert cache.exists() and info1["lines"] >= 46 and info1["batches"] == 2
+    L = hipdrv.lib()
+    n = hipdrv.C.c_int(0)
+    assert L.yolo2_hip_plan_cache_check(str(cache).encode(), info1["hash"], hipdrv.C.byref(n)) == hipdrv.YOLO2_SUCCESS and n.value == info1["lines"]
+    second, info2, _ = run(model, "weight cache", True)
+    assert info2["hash"] == info1["hash"] and info2["lines"] == info1["lines"]
+    for batch in (1, 2):
+        assert second[batch][0] == first[batch][0], batch                       # identical conv_plan_strings
+        assert np.array_equal(second[batch][1], first[batch][1])
+        for f in range(batch):
+            assert np.array_equal(first[batch][1][f].reshape(-1), want[f]), (batch, f)
+    # stale: the same file, another weight set -> refused as a whole, timed again, rewritten for the new set
+    other = synth.SynthModel(seed=4, gain=1.3)
+    third, info3, _ = run(other, "autotuned in this process", False)
+    assert info3["hash"] != info1["hash"]
+    ri = orclib.forward_i16(other, frames[0])[0]
+    assert np.array_equal(third[1][1][0].reshape(-1), ri)
+    assert L.yolo2_hip_plan_cache_check(str(cache).encode(), info1["hash"], None) == hipdrv.YOLO2_ERROR
+    assert L.yolo2_hip_plan_cache_check(str(cache).encode(), info3["hash"], None) == hipdrv.YOLO2_SUCCESS
+    # damaged: one flipped digit inside a bound line -> checksum mismatch -> refused; the result is still the oracle's
+    txt = cache.read_text()
+    i = txt.index("bound 7 ") + len("bound 7 ")
+    cache.write_text(txt[:i] + ("1" if txt[i] != "1" else "2") + txt[i + 1:])
+    fourth, info4, _ = run(other, "autotuned in this process", False)
+    assert np.array_equal(fourth[1][1][0].reshape(-1), ri)
+    # ... and an unwritable location costs nothing but the write
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.set_plan_cache("/nonexistent-dir/x.y2plan")
+    ctx.load_model(other)
+    r, _ = ctx.run_batch_host(frames[:1])
+    assert np.array_equal(r[0].reshape(-1), ri)
+    ctx.close()
+
+
+def test_ks_scratch_is_sized_from_the_accepted_plans():
+    """66 MB of triple scratch per frame were allocated for every context of <= 4 frames whether or not a layer ran the
+    K-split kernel.  Now: none with the K-split switched off (option no_ks), and with the plan table's batch-1 plans exactly the
+    largest ks x items x pixels x 24 among them - visible through device memory, and through the result staying bit-exact."""
+    import torch
+    model = synth.SynthModel(seed=1)
+    frame = synth.frames(7, 1)
+    free0 = torch.cuda.mem_get_info(0)[0]
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.set_option("no_ks", 1)
+    ctx.load_model(model)
+    ctx.set_batch(1)
+    r1, _ = ctx.run_batch_host(frame)
+    used_no_ks = free0 - torch.cuda.mem_get_info(0)[0]
+    ctx.close()
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_model(model)
+    ctx.set_batch(1)
+    ks = {o: -ctx.conv_launch_info(o)["pixels_per_lane"] for o in range(23) if ctx.conv_launch_info(o)["pixels_per_lane"] < 0}
+    r2, _ = ctx.run_batch_host(frame)
+    used_ks = free0 - torch.cuda.mem_get_info(0)[0]
+    ctx.close()
+    assert np.array_equal(r1, r2) and np.array_equal(r1[0].reshape(-1), FULL["i16/std/region_raw_i16"])
+    assert ks, "the batch-1 plan table uses the K-split kernel on some layers"
+    need = max(S * ((net.CONVS[o].n + 3) // 4) * net.CONVS[o].out_h * net.CONVS[o].out_w * 24 for o, S in ks.items())
+    # within allocator granularity (2 MiB pages) of the exact need; round 3 held 66.5 MB regardless
+    assert abs((used_ks - used_no_ks) - need) <= (4 << 20), (used_ks - used_no_ks, need)
+    assert need < 16 * 24 * 64 * 2704

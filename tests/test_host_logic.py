@@ -261,14 +261,115 @@ def test_bench_failure_containment_world2_gloo(fail_rank):
         assert r[2] == [[0.0, 10.0], [1.0, 11.0]]
 
 
-def test_fp16_launch_path_reads_no_environment():
-    """The fp16 kernel-family switches are latched once per weight load (F16Switches::from_env); run_batch_fp16 and the table
-    builder's selection logic must not call getenv (15 getenv sites per conv layer per call)."""
-    src = open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "yolo2_fp16.hip")).read()
-    body = src[src.index("static int build_f16_plan"):]
-    sel, run = body[:body.index("P.batch = B;")], body[body.index('extern "C" int yolo2_hip_run_batch_fp16('):]
-    assert "getenv" not in sel and "getenv" not in run
-    assert src.count("from_env()") >= 2 and "getenv" in src[src.index("static F16Switches from_env"):src.index("struct F16Step;")]
+def test_no_planning_or_launch_path_reads_the_environment():
+    """26 YOLO2_* variables were read at plan time (several per plan_conv call), 4 more on the fp16 side.  Now ONE
+    option set per context (Y2Options, y2_internal.hpp) is filled from the environment inside yolo2_hip_create and changed only by
+    yolo2_hip_set_option: the only getenv in the library's sources is Y2Options::from_env (yolo2_plan.hip)."""
+    csrc = os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        src = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        if f == "yolo2_plan.hip":
+            assert code.count("getenv(") == 1 and "getenv(" in code[code.index("Y2Options Y2Options::from_env()"):code.index("std::string Y2Options::describe()")]
+        else:
+            assert "getenv" not in code, f
+    plan = open(os.path.join(csrc, "yolo2_fp16.hip")).read()
+    assert "F16Switches::from_options(c->opt)" in plan
+
+
+def test_options_are_named_validated_and_parsed_once(monkeypatch):
+    """yolo2_hip_set_option on the process-wide set (ctx = NULL: what the driver tier plans with): names are checked, values are
+    range-checked, NULL restores the default; README.md documents every name the library knows."""
+    L = hipdrv.lib()
+    so = lambda n, v: L.yolo2_hip_set_option(None, n, v)
+    assert so(b"force_path", b"3") == hipdrv.YOLO2_SUCCESS and so(b"force_path", None) == hipdrv.YOLO2_SUCCESS
+    assert so(b"force_path", b"7") == hipdrv.YOLO2_ERROR and b"out of range" in L.yolo2_hip_last_error()
+    assert so(b"force_path", b"x") == hipdrv.YOLO2_ERROR
+    assert so(b"no_such_switch", b"1") == hipdrv.YOLO2_ERROR and b"no_such_switch" in L.yolo2_hip_last_error()
+    assert so(b"no_ks", b"1") == hipdrv.YOLO2_SUCCESS and so(b"no_ks", b"0") == hipdrv.YOLO2_SUCCESS
+    src = open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "yolo2_plan.hip")).read()
+    names = set(re.findall(r'\{"([a-z0-9_]+)", &Y2Options::', src))
+    assert len(names) >= 40
+    readme = open(os.path.join(ROOT, "README.md")).read()
+    missing = sorted(n for n in names if f"`{n}`" not in readme)
+    assert not missing, f"README.md does not document: {missing}"
+
+
+def test_ksplit_scratch_rule_on_plain_numbers():
+    """VERDICT r3 item 6.  Round 3's GPU memory fault (gpurun_out/r3f/b64_hi.err, pytest abort in test_fullnet_ksplit_across_workgroups)
+    was k_conv_i16_ks storing its triples past / without the context's scratch.  The rule plan_conv applies to every K-split plan and
+    launch_conv applies again before the launch, replayed without a GPU: (a) the over-capacity case - round 3 sized the scratch for
+    two layer shapes (16 splits x 64 items x 169 pixels), then planned 16 splits of a 52 x 52 layer into it; (b) the no-scratch case -
+    a batch-64 lane context never allocates scratch (cap 0) but carried a forced ks field."""
+    L = hipdrv.lib()
+    chk = lambda *a: L.yolo2_hip_i16_plan_check(*a)
+    r3_scratch = 16 * 24 * 256 * 169                       # what round 3 first allocated: 16 splits of the 13 x 13 x 1024 layers
+    assert chk(16, 256, 169, r3_scratch) == hipdrv.YOLO2_SUCCESS
+    assert chk(16, 64, 2704, r3_scratch) == hipdrv.YOLO2_ERROR          # layer 8/10 (52 x 52 x 256): (a) over capacity
+    assert b"do not fit" in L.yolo2_hip_last_error()
+    assert chk(8, 64, 2704, 8 * 24 * 64 * 2704) == hipdrv.YOLO2_SUCCESS and chk(8, 64, 2704, 8 * 24 * 64 * 2704 - 1) == hipdrv.YOLO2_ERROR
+    assert chk(2, 64, 2704 * 22, 0) == hipdrv.YOLO2_ERROR               # (b): a 22-frame lane of a batch-64 context has no scratch
+    assert b"no triple scratch" in L.yolo2_hip_last_error()
+    for s in (0, 1, 3, 5, 32, -4):
+        assert chk(s, 64, 169, 1 << 30) == hipdrv.YOLO2_ERROR
+    assert chk(4, 0, 169, 1 << 30) == hipdrv.YOLO2_ERROR and chk(4, 64, 0, 1 << 30) == hipdrv.YOLO2_ERROR
+    # what the scratch is sized for today: 16 splits of every layer at <= 52 x 52, per frame, batches <= 4
+    for frames in (1, 2, 4):
+        cap = 16 * 24 * 64 * 2704 * frames
+        for cg, npix in ((64, 2704), (128, 676), (256, 169), (256, 169)):
+            assert chk(16, cg, npix * frames, cap) == hipdrv.YOLO2_SUCCESS
+    # the launcher refuses as well: launch_conv returns YOLO2_ERROR for a ks plan without fitting scratch (source check; the GPU
+    # suite's test_fullnet_ksplit_across_workgroups drives it for real)
+    src = open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "yolo2_int16.hip")).read()
+    body = src[src.index("static int launch_conv("):src.index("// Resolve the per-layer Q values")]
+    assert "if (p.ks) {" in body and "!ks_trip || !y2_ks_fits(p.ks, p.args.CGout, p.args.npix, ks_trip_bytes)" in body and "not launched" in body
+
+
+def _cache_text(hash_, lines, bounds_mb=None):
+    """A weight-side plan cache as the library writes it (yolo2_plan.hip Y2PlanCache::save), built by hand."""
+    def fnv(data, h=1469598103934665603):
+        for b in data:
+            h = ((h ^ b) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        return h
+    body = "Y2PLAN 2 gfx950\n# comment\n" + f"hash {hash_:016x}\n"
+    for o, n in enumerate(net.BIAS_LEN):
+        mb = (n + 31) // 32 if bounds_mb is None else bounds_mb
+        body += f"bound {o} 1000 50 {mb}" + " 900 40 300 4 2" * mb + "\n"
+    for ln in lines:
+        body += "plan " + ln + "\n"
+    return body + f"sum {fnv(body.encode()):016x}\n"
+
+
+def test_weight_side_plan_cache_stale_or_damaged_costs_time_not_correctness(tmp_path):
+    """SURVEY 8(f).2 / VERDICT r3 item 5: <weights>.y2plan holds bounds, forms and timed plans of ONE weight set.  The loader takes
+    it only if header, weight hash and body checksum all match; here on files built by hand, no GPU: the intact file is accepted, a
+    stale one (other hash), a damaged one (one flipped digit), a truncated one, one with an out-of-range plan line, one with trailing
+    data and a file of another format are each refused as a whole - the loader then computes the bounds and times the batch as if
+    no file existed (tests/test_gpu_parity.py::test_weight_side_plan_cache_* runs that on the GPU)."""
+    L = hipdrv.lib()
+    n = hipdrv.C.c_int(0)
+    chk = lambda path, h: L.yolo2_hip_plan_cache_check(str(path).encode(), h, hipdrv.C.byref(n))
+    H = 0x1234ABCD5678EF01
+    good = tmp_path / "good.y2plan"
+    lines = ["1 0 0 3 1 0 0 1 0 1 0 0", "1 2 0 4 2 27306 0 1 0 0 0 0", "1 23 0 4 1 0 0 1 0 0 0 8"]
+    good.write_text(_cache_text(H, lines))
+    assert chk(good, H) == hipdrv.YOLO2_SUCCESS and n.value == 3
+    assert chk(good, H + 1) == hipdrv.YOLO2_ERROR and b"another weight set" in L.yolo2_hip_last_error()            # stale
+    txt = good.read_text()
+    bad = tmp_path / "flip.y2plan"
+    bad.write_text(txt.replace("bound 5 1000", "bound 5 1001"))
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR and b"checksum" in L.yolo2_hip_last_error()                           # damaged
+    bad.write_text(txt[:len(txt) // 2])
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR                                                                          # truncated
+    bad.write_text(_cache_text(H, ["1 0 0 3 3 0 0 1 0 1 0 0"]))
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR and b"bad plan line" in L.yolo2_hip_last_error()                        # P = 3 is no tile shape
+    bad.write_text(txt + "plan 1 4 0 4 1 0 0 1 0 0 0 0\n")
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR                                                                          # data after the checksum
+    bad.write_text(txt.replace("Y2PLAN 2 gfx950", "Y2PLAN 1 gfx942"))
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR
+    assert chk(tmp_path / "missing.y2plan", H) == hipdrv.YOLO2_ERROR and b"no cache file" in L.yolo2_hip_last_error()
+    bad.write_text(_cache_text(H, lines).replace("bound 22 ", "bound 23 "))
+    assert chk(bad, H) == hipdrv.YOLO2_ERROR
 
 
 def test_committed_plan_table_is_well_formed():

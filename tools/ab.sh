@@ -11,7 +11,13 @@ done
 python3 - "$OUT" $N <<'PY' | tee "$OUT/summary.txt"
 import json, sys
 out, n = sys.argv[1], int(sys.argv[2])
+src = {}
 for k in "ab":
-    v = [json.load(open(f"{out}/{k}_{i}.json"))["value"] for i in range(1, n + 1)]
-    print(k, "default" if k == "a" else "alt    ", " ".join(f"{x:8.1f}" for x in v), f"  median {sorted(v)[len(v)//2]:.1f}")
+    recs = [json.load(open(f"{out}/{k}_{i}.json")) for i in range(1, n + 1)]
+    v = [r["value"] for r in recs]
+    src[k] = sorted({r["config"].get("conv_plan_source", "?") for r in recs})
+    print(k, "default" if k == "a" else "alt    ", " ".join(f"{x:8.1f}" for x in v), f"  median {sorted(v)[len(v)//2]:.1f}   plan source: {src[k]}")
+# both arms must run the SAME kernel selection (a variant that silently autotuned was compared with a baseline on the plan table)
+if src["a"] != src["b"]:
+    sys.exit(f"A/B invalid: the arms planned differently ({src})")
 PY

@@ -16,8 +16,14 @@ done
 python3 - "$OUT" $N default "${LIBS[@]}" <<'PY' | tee "$OUT/summary.txt"
 import json, os, sys
 out, n = sys.argv[1], int(sys.argv[2])
+src = {}
 for lib in sys.argv[3:]:
     k = os.path.basename(lib).replace(".so", "")
-    v = [json.load(open(f"{out}/{k}_{i}.json"))["value"] for i in range(1, n + 1)]
-    print(f"{k:24s}", " ".join(f"{x:8.1f}" for x in v), f"  median {sorted(v)[len(v)//2]:.1f}")
+    recs = [json.load(open(f"{out}/{k}_{i}.json")) for i in range(1, n + 1)]
+    v = [r["value"] for r in recs]
+    src[k] = sorted({r["config"].get("conv_plan_source", "?") for r in recs})
+    print(f"{k:24s}", " ".join(f"{x:8.1f}" for x in v), f"  median {sorted(v)[len(v)//2]:.1f}   plan source: {src[k]}")
+# every arm must run the SAME kernel selection (variants that silently autotuned were compared with a baseline on the plan table)
+if len({tuple(s) for s in src.values()}) > 1:
+    sys.exit(f"A/B invalid: the arms planned differently ({src})")
 PY

@@ -16,6 +16,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/yolo2_hip.h"
@@ -33,6 +38,86 @@ int y2_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3))
         hipError_t e_ = (expr);                                                                  \
         if (e_ != hipSuccess) return fail(code, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
+
+
+// ---------------------------------------------------------------------------- options (yolo2_plan.hip)
+//
+// Every switch that steers kernel selection, lanes or planning lives here, ONE object per context: filled from the environment
+// (YOLO2_<NAME>, upper case) once, when the context is created, and changed on a live context only through
+// yolo2_hip_set_option(ctx, "<name>", "<value>").  Nothing on a planning or launch path calls getenv (round 3 read 26 variables at
+// plan time, several of them per plan_conv call).  A lane inherits its parent's object.  README.md lists the names.
+// Groups: (a) planning knobs a deployment may set (autotune, plan_file, plan_write, lanes, no_lanes, lane_priority, verbose);
+// (b) A/B switches of kernel families (no_* / f16_*); (c) test hooks that force one kernel shape everywhere (force_*, f32_p).
+struct Y2Options {
+    // (a)
+    int autotune = -1;            // -1: weight cache, then plan table, then timing; 0: static defaults, nothing timed; 1: always time
+    std::string plan_file;        // replaces config/plan_gfx950.txt next to the library
+    std::string plan_write;       // append every timed plan to this file (tools/make_plan.py)
+    int lanes = 0;                // int16 lanes (0 = the default rule: 3 for batches 48..127, 2 from batch 16)
+    bool no_lanes = false;
+    std::string lane_split;       // diagnostic: "20,22,22"
+    int lane_priority = 1;        // 0: lanes at default stream priority, lane 0 on the caller's stream (round-3 interim design)
+    bool verbose = false;
+    bool no_plan_cache = false;   // ignore a bound weight-side plan cache
+    // (b)
+    int splitk = -1;              // -1 tuned; 0 no K-split of either kind; 1 the lane-split kernel wherever legal
+    int poolfuse = -1;            // 1: conv + pool fused wherever legal
+    bool no_poolfuse = false, no_hiacc = false, no_ks = false, no_w16 = false, no_grp = false, no_xcd_remap = false, splitk_no_pack = false;
+    int f16_lanes = 2;
+    bool f16_no_lanes = false, f16_no_mfma0 = false, f16_no_glds = false, f16_no_poolfuse = false, f16_no_halo = false, f16_no_persist = false,
+         f16_persist_all = false, f16_ring_all = false, f16_no_ring = false, f16_no_c32 = false, f16_m16 = false, f16_w8 = false, f16_no_wide = false,
+         f16_no_fuse1x1 = false, f16_no_rw = false, f16_no_im2col0 = false;
+    int stamp_layer = -1;
+    // (c)
+    int force_path = -1, force_p = 0, force_ks = 0, f32_p = 0;
+    bool force_w16 = false, force_hiacc = false;
+
+    static Y2Options from_env();
+    // 0 = set, -1 = unknown name / bad value.  value NULL or "" restores the default.
+    int set(const char *name, const char *value);
+    // the settings that differ from the defaults, "name=value name=value" ("" if none): what bench.py discloses
+    std::string describe() const;
+    // switches that ask for a plan the committed table / the weight cache do not hold: those are bypassed
+    bool steered() const { return splitk >= 0 || poolfuse >= 0 || no_poolfuse || no_w16 || no_hiacc || no_ks || no_grp || no_xcd_remap; }
+};
+const Y2Options &y2_process_options();   // from the environment, parsed once: the context-less driver tier and process-wide latches
+
+// ---------------------------------------------------------------------------- launch plans as data (yolo2_plan.hip)
+
+// One launch of a conv layer as the plan table / the weight cache store it:  B L S path P pad splitk pp w16 fuse hiacc ks
+struct Y2PlanLine { int path, P, pad, splitk, pp, w16, fuse, hiacc, ks; };
+typedef std::pair<int, std::pair<int, int>> Y2PlanKey;   // (B, (L, S))
+// parses and range-checks one line (a line outside what the planner can produce is rejected); false: not a plan line
+bool y2_plan_line_parse(const char *text, Y2PlanKey *key, Y2PlanLine *pl);
+// the committed table (config/plan_gfx950.txt next to the library, or opt.plan_file): loaded once per file name
+bool y2_plan_table_has_batch(const Y2Options &opt, int B);
+bool y2_plan_table_lookup(const Y2Options &opt, int B, int L, int S, Y2PlanLine *out);
+
+// The K-split-across-workgroups kernel's scratch rule on plain numbers (also exported: yolo2_hip_i16_plan_check):
+// `splits` triples of 24 bytes per output item; cap = 0 (a context without scratch) refuses every split.
+bool y2_ks_fits(int splits, int cg_out, int npix, size_t cap_bytes);
+size_t y2_ks_bytes(int splits, int cg_out, int npix);
+
+// The weight-side cache: one small text file beside a weight set, keyed by a hash of the blobs and Q tables,
+// holding what loading and planning would otherwise recompute - the per-block bounds behind the arithmetic-form proofs (so
+// k_weight_bound* is skipped), the forms and scale shifts derived from them (re-derived and compared at load: a mismatch drops the
+// file) and the conv plan of every batch this weight set has been timed for (so the autotune is skipped and every process runs
+// the same kernels).  A missing, stale or damaged file costs time, never correctness: hash and body checksum must both match.
+struct Y2PlanCache {
+    std::mutex mu;
+    std::string path;
+    uint64_t hash = 0;            // of the weight set currently loaded (0 = none yet)
+    bool bounds_valid = false;    // the file matched this weight set and its bounds were used
+    struct Bounds { int maxsum = 0, maxbias = 0; std::vector<int> sum_mb, bias_mb, abs_mb, form, scale; };
+    Bounds bounds[YOLO2_N_CONV];
+    std::map<Y2PlanKey, Y2PlanLine> lines;
+    std::map<int, int> per_batch;
+    bool dirty = false;
+    // reads `path`; true iff header, hash and checksum match `want_hash` (then bounds / lines are filled)
+    bool load(uint64_t want_hash, std::string *why);
+    bool save();                   // temp file + rename; false (and nothing else) if the directory is not writable
+};
+uint64_t y2_hash_bytes(uint64_t seed, const void *data, size_t n);   // host side: Q tables, file body
 
 // ---------------------------------------------------------------------------- model table (yolo2_hip.hip)
 
@@ -65,6 +150,7 @@ struct ConvPlan {
     int splitk_ok = 0;         // the loader proved the split-K bounds for these blocks (|t| < 2^29, sums < 2^30)
     int splitk = 0;            // small batches: S K-splits x 64/S pixels per wavefront, shuffle-combined (k_conv_i16_splitk); 0 or S
     int splitk_pp = 1;         // pixels per lane of the split-K kernel (2: two pixel tiles share the staged weight slices)
+    int splitk_pack = 0;       // the lane-split kernel carries packed int16 triples (form D launches)
     size_t ks_cap = 0;         // bytes of the context's triple scratch: plan_conv refuses a split whose triples would not fit
     int ks = 0;                // single frames: K-split across workgroups (k_conv_i16_ks + k_ks_finalize); 0 or the number of splits
     int hiacc = 0;             // form D launches only: 1 = the kernel keeps one accumulator register per channel (no v_perm: MODE 5)
@@ -121,6 +207,8 @@ struct F16Plan;   // yolo2_fp16.hip: the per-context launch table of the fp16 pa
 struct yolo2_hip_ctx {
     PipeBufs pipe;
     int device = 0;
+    Y2Options opt;                     // parsed once at creation (environment), changed only by yolo2_hip_set_option; lanes copy it
+    std::shared_ptr<Y2PlanCache> plan_cache;   // weight-side cache bound by yolo2_hip_set_plan_cache (lanes share the parent's)
     bool weights_loaded = false;
     short *wpk = nullptr;      // all layers, packed
     short *bias_pk = nullptr;  // all layers, padded to 32
@@ -131,9 +219,10 @@ struct yolo2_hip_ctx {
     std::vector<ConvPlan> extra[32];   // further launches for blocks that need another arithmetic form
     std::vector<int> maxsum_mb[YOLO2_N_CONV], maxbias_mb[YOLO2_N_CONV], maxabs_mb[YOLO2_N_CONV];
     std::vector<signed char> wscale_mb[YOLO2_N_CONV];   // log2 of the factor each block's packed weights currently carry (form D)
+    std::vector<signed char> form_mb[YOLO2_N_CONV];     // arithmetic form resolve_q chose per block of 32 output channels
     int *mb_lists = nullptr;           // device: block index lists of all split layers
-    int plan_source = 0;               // how set_batch planned the conv launches: 1 plan table, 2 timed (autotune), 3 static defaults
-    int *ks_trip = nullptr;            // device scratch of the K-split-across-workgroups kernel (triples of every split), grown on demand
+    int plan_source = 0;               // how set_batch planned the conv launches: 1 plan table, 2 timed (autotune), 3 static defaults, 4 forced, 5 weight cache
+    int *ks_trip = nullptr;            // device scratch of the K-split-across-workgroups kernel (triples of every split): sized from the accepted plans
     size_t ks_trip_bytes = 0;
     // Lanes: a batch is run as part-batches on internal streams (forked from / joined to the
     // caller's stream with events).  Every layer is then several concurrent launches, and the idle tail of

@@ -124,7 +124,7 @@ extern "C" void yolo2_accel_cleanup(void)
     if (!g_drv.inited) return;
     (void)hipSetDevice(g_drv.device);
     (void)hipDeviceSynchronize();
-    if (getenv("YOLO2_VERBOSE")) fprintf(stderr, "[yolo2_hip] driver served %ld layer calls\n", g_drv.calls);
+    if (y2_process_options().verbose) fprintf(stderr, "[yolo2_hip] driver served %ld layer calls\n", g_drv.calls);
     y2_drv_release_i16();
     g_drv.inited = false;
 }

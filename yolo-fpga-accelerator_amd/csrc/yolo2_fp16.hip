@@ -19,24 +19,27 @@ using namespace y2;
 //
 // Which kernel runs which layer is decided ONCE per (context, batch) and stored as a table of steps; a pass is a walk over
 // that table (no environment look-ups, no selection logic on the launch path).  The A/B switches of the kernel families
-// (YOLO2_F16_*: tests and tools/abenv.sh use them) are read once, when the weights are loaded, into F16Switches.
+// (options f16_* of the context, from YOLO2_F16_* at context creation or yolo2_hip_set_option: tests and tools/abenv.sh use
+// them) are latched once, when the weights are loaded, into F16Switches.
 
 struct F16Switches {
     int lanes = 2;            // YOLO2_F16_LANES=n (1..8), YOLO2_F16_NO_LANES -> 1
     bool no_mfma0 = false, no_glds = false, no_poolfuse = false, no_halo = false, no_persist = false, persist_all = false;
     bool ring_all = false, no_ring = false, no_c32 = false, m16 = false, w8 = false, no_wide = false;
     int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
-    static F16Switches from_env()
+    bool verbose = false;
+    bool no_fuse1x1 = false, no_rw = false, no_im2col0 = false;
+    static F16Switches from_options(const Y2Options &o)   // the context's option set (y2_internal.hpp), latched at weight load
     {
         F16Switches s;
-        auto on = [](const char *n) { return getenv(n) != nullptr; };
-        if (const char *e = getenv("YOLO2_F16_LANES")) s.lanes = std::max(1, std::min(8, atoi(e)));
-        if (on("YOLO2_F16_NO_LANES")) s.lanes = 1;
-        s.no_mfma0 = on("YOLO2_F16_NO_MFMA0"); s.no_glds = on("YOLO2_F16_NO_GLDS"); s.no_poolfuse = on("YOLO2_F16_NO_POOLFUSE");
-        s.no_halo = on("YOLO2_F16_NO_HALO"); s.no_persist = on("YOLO2_F16_NO_PERSIST"); s.persist_all = on("YOLO2_F16_PERSIST_ALL");
-        s.ring_all = on("YOLO2_F16_RING_ALL"); s.no_ring = on("YOLO2_F16_NO_RING"); s.no_c32 = on("YOLO2_F16_NO_C32");
-        s.m16 = on("YOLO2_F16_M16"); s.w8 = on("YOLO2_F16_W8"); s.no_wide = on("YOLO2_F16_NO_WIDE");
-        if (const char *e = getenv("YOLO2_STAMP_LAYER")) s.stamp_layer = atoi(e);
+        s.lanes = o.f16_no_lanes ? 1 : o.f16_lanes;
+        s.no_mfma0 = o.f16_no_mfma0; s.no_glds = o.f16_no_glds; s.no_poolfuse = o.f16_no_poolfuse;
+        s.no_halo = o.f16_no_halo; s.no_persist = o.f16_no_persist; s.persist_all = o.f16_persist_all;
+        s.ring_all = o.f16_ring_all; s.no_ring = o.f16_no_ring; s.no_c32 = o.f16_no_c32;
+        s.m16 = o.f16_m16; s.w8 = o.f16_w8; s.no_wide = o.f16_no_wide;
+        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_im2col0 = o.f16_no_im2col0;
+        s.stamp_layer = o.stamp_layer;
+        s.verbose = o.verbose;
         return s;
     }
 };
@@ -160,7 +163,7 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     y2_f16_plan_free(c);
     c->f16_plan = new (std::nothrow) F16Plan();
     if (!c->f16_plan) return fail(YOLO2_ERROR, "out of host memory");
-    c->f16_plan->sw = F16Switches::from_env();   // the ONLY place the fp16 path reads its switches
+    c->f16_plan->sw = F16Switches::from_options(c->opt);   // the ONLY place the fp16 path reads its switches
     if (c->wh) (void)hipFree(c->wh);
     if (c->biasf) (void)hipFree(c->biasf);
     c->wh = nullptr;
@@ -478,7 +481,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         }
     }
     P.batch = B;
-    if (getenv("YOLO2_VERBOSE"))   // (plan construction, not the launch path)
+    if (sw.verbose)   // (plan construction, not the launch path)
         for (const F16Step &s : P.steps)
             fprintf(stderr, "[yolo2_hip] fp16 plan B=%d L%-2d %-30s grid %u block %u lds %u\n", B, s.layer, s.kernel, s.grid.x, s.block.x, s.lds);
     return YOLO2_SUCCESS;

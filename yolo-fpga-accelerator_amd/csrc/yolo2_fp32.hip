@@ -226,7 +226,7 @@ static int ensure_f32_path(yolo2_hip_ctx *c, int B)
     c->f_out[27] = c->f_cat;
     c->f32_batch = B;
     // pixels per lane: timed once per layer (the arithmetic does not depend on it)
-    const char *fp = getenv("YOLO2_F32_P");   // test hook: 1 / 2 / 4 for every layer
+    const int fp = c->opt.f32_p;   // test hook: 1 / 2 / 4 for every layer (0: timed)
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0), YOLO2_ERROR);
     HIP_TRY(hipEventCreate(&e1), YOLO2_ERROR);
@@ -240,7 +240,7 @@ static int ensure_f32_path(yolo2_hip_ctx *c, int B)
         float best = 1e30f;
         int bestP = 2;
         for (int P = 1; P <= 4; P <<= 1) {
-            if (fp && atoi(fp) != P) continue;
+            if (fp && fp != P) continue;
             ConvPlan cand;
             plan_conv_f32(cand, l, tin.g, tout.g.cg_stride, out_base, P);
             if (cand.P != P) continue;

@@ -18,7 +18,7 @@ using namespace y2;
 // ---------------------------------------------------------------------------- errors
 
 static thread_local char g_err[512] = "";
-static const bool g_verbose = getenv("YOLO2_VERBOSE") != nullptr;   // latched once: no getenv on any launch path
+static const bool g_verbose = y2_process_options().verbose;   // latched once: no getenv on any launch path
 
 int y2_fail(int code, const char *fmt, ...)
 {
@@ -140,6 +140,7 @@ extern "C" int yolo2_hip_create(int device, yolo2_hip_ctx **out)
     yolo2_hip_ctx *c = new (std::nothrow) yolo2_hip_ctx();
     if (!c) return fail(YOLO2_ERROR, "out of host memory");
     c->device = device;
+    c->opt = Y2Options::from_env();   // the ONLY read of the YOLO2_* switches for this context (yolo2_hip_set_option changes them later)
     *out = c;
     return YOLO2_SUCCESS;
 }
@@ -248,7 +249,7 @@ static int pipe_ensure(PipeBufs &p, size_t host_in, size_t dev_in, int batch, bo
     return YOLO2_SUCCESS;
 }
 
-static const bool g_lane_prio = !(getenv("YOLO2_LANE_PRIORITY") && atoi(getenv("YOLO2_LANE_PRIORITY")) == 0);   // latched: set_batch time only
+static const bool g_lane_prio = y2_process_options().lane_priority != 0;   // process-wide (the priority pools are): latched once
 
 bool y2_lane0_own_stream() { return g_lane_prio; }
 

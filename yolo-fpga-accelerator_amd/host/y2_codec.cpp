@@ -298,6 +298,11 @@ struct Jpeg {
             hmax = c.h > hmax ? c.h : hmax;
             vmax = c.v > vmax ? c.v : vmax;
         }
+        // sampling factors that do not divide the largest one (H = 4,3,1; 3,2,1): the up-sampler's integer ratio hmax / h would be
+        // too small and a row of `width` samples would be read from a plane row of only mcu_x * h * 8 (heap read past
+        // the plane under ASan).  stb 2.19 survives such files on 15 bytes of over-allocation, later stb versions reject them; so do we.
+        for (int i = 0; i < ncomp; ++i)
+            if (hmax % comp[i].h != 0 || vmax % comp[i].v != 0) bad("Corrupt JPEG: bad H/V");
         mcu_x = (width + hmax * 8 - 1) / (hmax * 8);
         mcu_y = (height + vmax * 8 - 1) / (vmax * 8);
         for (int i = 0; i < ncomp; ++i) {

@@ -68,6 +68,7 @@ struct AppConfig {
     int chunk_batches = 4;             // batches per device and accelerator call (streaming)
     int decode_threads = 0;            // image decode pool; 0 = all host cores
     bool strict = false;               // streaming: stop at the first undecodable input instead of skipping the frame
+    bool plan_cache = true;            // int16: keep bounds / forms / timed conv plans of this weight set in <weights>/weights_reorg_int16.bin.y2plan
     bool streaming() const { return !input_list.empty() || !input_dir.empty() || !video_raw.empty(); }
 };
 
@@ -102,6 +103,8 @@ void print_usage(const char *prog)
         "  --chunk-batches <n>   Batches per device and accelerator call (default 4)\n"
         "  --decode-threads <n>  Host threads decoding images ahead of the accelerators (default: all cores; one pool feeds every device)\n"
         "  --strict              Stop at the first input that cannot be read or decoded (default: log it, skip the frame, go on)\n"
+        "  --no-plan-cache       int16: do not read / write <weights>/weights_reorg_int16.bin.y2plan (the weight set's bounds, forms and\n"
+        "                        timed conv plans; with it a weight set is timed once and every later run uses the same kernels)\n"
         "  --post <gpu|host>     Where region + boxes + NMS run (default gpu)\n",
         prog);
 }
@@ -147,6 +150,7 @@ AppConfig parse_args(int argc, char **argv)
         else if (arg == "--chunk-batches" && need("")) cfg.chunk_batches = std::max(1, std::atoi(argv[++i]));
         else if (arg == "--decode-threads" && need("")) cfg.decode_threads = std::atoi(argv[++i]);
         else if (arg == "--strict") cfg.strict = true;
+        else if (arg == "--no-plan-cache") cfg.plan_cache = false;
         else if (arg == "--post" && need("")) {
             cfg.post = argv[++i];
             if (cfg.post != "gpu" && cfg.post != "host") { std::fprintf(stderr, "Unsupported --post %s (gpu | host)\n", cfg.post.c_str()); std::exit(1); }
@@ -468,6 +472,11 @@ void run_stream(AppConfig cfg)
     if (yolo2_hip_multi_create(cfg.devices.data(), ndev, &m) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
     struct Guard { yolo2_hip_multi *m; ~Guard() { yolo2_hip_multi_destroy(m); } } guard{m};
     {
+        // the weight-side cache (include/yolo2_hip.h): beside the interchange file, one per weight set, shared by every device
+        if (cfg.plan_cache)
+            for (int i = 0; i < yolo2_hip_multi_num_devices(m); ++i)
+                if (yolo2_hip_set_plan_cache(yolo2_hip_multi_ctx(m, i), (cfg.weights_dir + "/weights_reorg_int16.bin.y2plan").c_str()) != YOLO2_SUCCESS)
+                    throw std::runtime_error(yolo2_hip_last_error());
         std::vector<int> wlen(yolo2_weight_len, yolo2_weight_len + YOLO2_N_CONV), blen(yolo2_bias_len, yolo2_bias_len + YOLO2_N_CONV);
         const y2h::WeightsI16 wp = y2h::load_weights_int16(cfg.weights_dir, wlen, blen);
         if (yolo2_hip_multi_load_weights_int16(m, wp.weights.data(), wp.weights.size(), wp.bias.data(), wp.bias.size(), wp.weight_q.data(),
@@ -476,6 +485,7 @@ void run_stream(AppConfig cfg)
             throw std::runtime_error(yolo2_hip_last_error());
     }
     std::printf("  weights on %d device(s)%s\n", yolo2_hip_multi_num_devices(m), yolo2_hip_multi_uses_rccl(m) ? " (RCCL broadcast)" : "");
+    auto plan_source_name = [](int s) { return s == 1 ? "plan table" : s == 2 ? "timed in this process" : s == 3 ? "static defaults" : s == 4 ? "forced" : s == 5 ? "weight cache" : "none"; };
     FILE *jf = nullptr;
     if (!cfg.jsonl_path.empty()) {
         jf = std::fopen(cfg.jsonl_path.c_str(), "w");
@@ -595,6 +605,7 @@ void run_stream(AppConfig cfg)
             yolo2_hip_ctx *ctx = yolo2_hip_multi_ctx(m, slot);
             // while the reader decodes its first chunk: plan the batch (activation tensors, lanes) on this device
             if (yolo2_hip_set_batch(ctx, cfg.batch) != YOLO2_SUCCESS) throw std::runtime_error(yolo2_hip_last_error());
+            if (slot == 0) std::printf("  conv plans: %s\n", plan_source_name(yolo2_hip_plan_source(ctx)));
             std::unique_ptr<Chunk> ck;
             std::vector<int16_t> region;
             std::vector<yolo2_hip_det> recs;
@@ -714,6 +725,8 @@ void run_detector(AppConfig cfg)
     } else {
         std::vector<int> wlen(yolo2_weight_len, yolo2_weight_len + YOLO2_N_CONV), blen(yolo2_bias_len, yolo2_bias_len + YOLO2_N_CONV);
         const y2h::WeightsI16 wp = y2h::load_weights_int16(cfg.weights_dir, wlen, blen);
+        if (cfg.plan_cache && yolo2_hip_set_plan_cache(ctx, (cfg.weights_dir + "/weights_reorg_int16.bin.y2plan").c_str()) != YOLO2_SUCCESS)
+            throw std::runtime_error(yolo2_hip_last_error());
         if (yolo2_hip_load_weights_int16(ctx, wp.weights.data(), wp.weights.size(), wp.bias.data(), wp.bias.size(), wp.weight_q.data(),
                                          (int)wp.weight_q.size(), wp.bias_q.data(), (int)wp.bias_q.size(), wp.act_q.data(),
                                          (int)wp.act_q.size()) != YOLO2_SUCCESS)

@@ -43,6 +43,8 @@ EXPORTS = [
     "yolo2_hip_rccl_info", "yolo2_hip_multi_rccl_info", "yolo2_hip_ctx_device", "yolo2_hip_alloc_on",
     "yolo2_hip_fp16_layer_kernel", "yolo2_hip_f16_store_check",
     "yolo2_hip_run_images_u8_dets", "yolo2_hip_multi_run_images_u8_dets", "yolo2_hip_set_fp16_lanes", "yolo2_hip_conv_plan_string", "yolo2_hip_plan_source",
+    "yolo2_hip_set_option", "yolo2_hip_options_string", "yolo2_hip_set_plan_cache", "yolo2_hip_plan_cache_info", "yolo2_hip_plan_cache_check",
+    "yolo2_hip_i16_plan_check",
 ]
 
 
@@ -131,6 +133,12 @@ def lib():
     L.yolo2_hip_postprocess_int16.argtypes = [vp, u64, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
     L.yolo2_hip_postprocess_f32.argtypes = [vp, u64, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
     L.yolo2_hip_shard_range.argtypes = [i32, i32, i32, pi32, pi32]
+    L.yolo2_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.yolo2_hip_options_string.argtypes = [vp, C.c_char_p, i32]
+    L.yolo2_hip_set_plan_cache.argtypes = [vp, C.c_char_p]
+    L.yolo2_hip_plan_cache_info.argtypes = [vp, C.POINTER(u64), pi32, pi32, pi32]
+    L.yolo2_hip_plan_cache_check.argtypes = [C.c_char_p, u64, pi32]
+    L.yolo2_hip_i16_plan_check.argtypes = [i32, i32, i32, C.c_size_t]
     L.yolo2_hip_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.yolo2_hip_multi_destroy.argtypes = [vp]
     L.yolo2_hip_multi_num_devices.argtypes = [vp]
@@ -439,7 +447,25 @@ class Yolo2Hip:
         return int(lib().yolo2_hip_num_lanes_fp16(self._h))
 
     def plan_source(self) -> str:
-        return {0: "none", 1: "plan table", 2: "autotuned in this process", 3: "static defaults", 4: "forced by a test hook"}[int(lib().yolo2_hip_plan_source(self._h))]
+        return {0: "none", 1: "plan table", 2: "autotuned in this process", 3: "static defaults", 4: "forced by a test hook",
+                5: "weight cache"}[int(lib().yolo2_hip_plan_source(self._h))]
+
+    def set_option(self, name: str, value=None):
+        """One named option of the context (include/yolo2_hip.h "options"); None restores the default."""
+        check(lib().yolo2_hip_set_option(self._h, name.encode(), None if value is None else str(value).encode()), f"yolo2_hip_set_option({name})")
+
+    def options(self) -> str:
+        buf = C.create_string_buffer(1024)
+        check(lib().yolo2_hip_options_string(self._h, buf, 1024), "yolo2_hip_options_string")
+        return buf.value.decode()
+
+    def set_plan_cache(self, path):
+        check(lib().yolo2_hip_set_plan_cache(self._h, None if path is None else str(path).encode()), "yolo2_hip_set_plan_cache")
+
+    def plan_cache_info(self):
+        h, used, n, nb = C.c_uint64(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().yolo2_hip_plan_cache_info(self._h, C.byref(h), C.byref(used), C.byref(n), C.byref(nb)), "yolo2_hip_plan_cache_info")
+        return {"hash": h.value, "bounds_from_file": bool(used.value), "lines": n.value, "batches": nb.value}
 
     def conv_plan(self, ord_: int) -> str:
         buf = C.create_string_buffer(256)
