@@ -261,6 +261,23 @@ int yolo2_hip_num_lanes_fp16(yolo2_hip_ctx *ctx);
  * ALONE for the per-kernel roofline object. */
 int yolo2_hip_set_fp16_lanes(yolo2_hip_ctx *ctx, int lanes);
 
+/* ------------------------------------------------------- "fp32 fast": the matrix-core path INSIDE the fp32 tolerance
+ *
+ * BASELINE.json: "MFMA used only on the fp16/fp32 path where conv is a true dense contraction ... detections ... within 1e-3
+ * box-coord tolerance for fp32".  The plain fp16 path is outside that tolerance (5.8e-3), the exact fp32 path is bit-identical
+ * but VALU-bound.  This entry computes the reference's fp32 arithmetic (hls/core/core_compute.cpp:121-172: per output
+ * bias + sum of w x, leaky x < 0 ? 0.1 x : x) on v_mfma_f32_32x32x16_f16 with every value carried as two halves
+ * hi = fp16(v), lo = fp16(v - hi) and every product taken as a_hi w_hi + a_lo w_hi + a_hi w_lo (fp32 accumulate; the dropped
+ * lo x lo term is 2^-22 relative): ~1e-6 relative error per layer instead of fp16's 5e-4, for 3x the MFMA work of the fp16 path.
+ * Same contract as yolo2_hip_run_batch_fp16: float CHW frames in HBM -> dense fp32 [batch][425][13][13] region tensor, enqueued on
+ * `stream`, needs yolo2_hip_load_weights_fp32*.  Not bit-exact with the reference (another summation order); the GPU tests hold
+ * every one of the 845 boxes of the fixture frames within 1e-3 in all four coordinates (measured: ~1e-5). */
+int yolo2_hip_run_batch_f32tol(yolo2_hip_ctx *ctx, uint64_t frames_dev, int batch, uint64_t region_dev, void *stream);
+int yolo2_hip_run_batch_f32tol_host(yolo2_hip_ctx *ctx, const float *frames, int batch, float *region);
+/* kernel the split-mode launch table runs for a layer / its lane count (after the first run at this batch) */
+const char *yolo2_hip_f32tol_layer_kernel(yolo2_hip_ctx *ctx, int layer_idx);
+int yolo2_hip_num_lanes_f32tol(yolo2_hip_ctx *ctx);
+
 /* 1 when conv layer `layer_idx` (0..31) runs fused with the 2x2 max pool after it (k_conv_i16_pool: the
  * full-resolution tensor is never written, except layer 16's, which also feeds the route), 0 otherwise.
  * Chosen per batch by set_batch (timed); YOLO2_NO_POOLFUSE=1 disables, YOLO2_POOLFUSE=1 forces it wherever legal. */
@@ -322,6 +339,9 @@ int yolo2_hip_plan_cache_check(const char *path, uint64_t weights_hash, int *n_l
  * numbers (no GPU): splits in {2,4,8,16} and splits x cg_out x npix x 24 <= cap_bytes; cap_bytes = 0 (a context without scratch:
  * batch > 4) refuses every split.  Round 3's GPU memory fault was this rule violated. */
 int yolo2_hip_i16_plan_check(int splits, int cg_out, int npix, size_t cap_bytes);
+/* Bytes of that scratch the context holds for its current batch: the largest splits x items x pixels x 24 among the plans that were
+ * accepted - 0 when no layer runs the K-split kernel (round 3 held 66 MB per frame for every context of <= 4 frames). */
+size_t yolo2_hip_ks_scratch_bytes(yolo2_hip_ctx *ctx);
 
 /* fp32 whole network in the reference's own arithmetic (what yolov2_hls_ps does at Precision::FP32,
  * hls/models/yolov2/yolo2_model.cpp:229-449: compute() fp32 branch core_compute.cpp:121-172 in its

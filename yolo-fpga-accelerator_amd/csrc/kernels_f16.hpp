@@ -55,7 +55,18 @@ struct ConvF16Args {
     // is ~30 instructions, and a halo-kernel lane needs 14 of them before its first MFMA
     unsigned mHW, sHW, mW, sW;
     int stamp;             // diagnostic builds (-DY2_STAMPS): this launch records its workgroups' timeline in y2_stamps
+    // split-fp16 ("fp32tol") mode, SPLIT instantiations only: every fp32 value v travels as hi = fp16(v), lo = fp16(v - hi) and an
+    // item holds three parts [hi | lo | hi] of split_n channels each (the weights are packed [w_hi | w_hi | w_lo] to match, so that the
+    // plain fp16 contraction over the tripled channels is a_hi w_hi + a_lo w_hi + a_hi w_lo: fp32 accuracy but for the 2^-22 lo x lo term).
+    // The epilogue stores channel ch of part p at out_ch_off + p * split_n + ch.
+    int split_n;
 };
+
+__device__ __forceinline__ void split_f32(float v, _Float16 &hi, _Float16 &lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);      // exact difference (hi is v rounded to 11 bits), then rounded to fp16
+}
 
 inline void set_fast_div(ConvF16Args &a)
 {
@@ -149,6 +160,38 @@ __device__ __forceinline__ void store_pooled(const _Float16 (*Ct)[CTROW], _Float
         for (int k = 1; k < 4; ++k) v = __builtin_elementwise_max(v, *reinterpret_cast<const half8_t *>(&Ct[4 * p + k][chunk * 8]));
         const int b = pq / OHW, r = pq - b * OHW, oy = r / OW, ox = r - oy * OW;
         *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + ox) * a.Cp_out + a.out_ch_off + ch0) = v;
+    }
+}
+
+// split mode: Ct holds the tile as FLOATS (bias + leaky applied, not yet rounded): the pool is a max of fp32 values, the winner is
+// split into (hi, lo) and stored to the three parts of the pooled item.  8 channels per thread and pooled pixel.
+template <int BM, int BN, int NT, int CTROW>
+__device__ __forceinline__ void store_pooled_split(const float (*Ct)[CTROW], _Float16 *__restrict__ out, const ConvF16Args &a, int tile,
+                                                   int n0, int tid)
+{
+    constexpr int CH = BN / 8, RPP = NT / CH, PR = BM / 4;
+    const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + chunk * 8;
+    if (ch0 >= a.n_store) return;
+    const int OW = a.W / 2, OHW = (a.H / 2) * OW;
+#pragma unroll
+    for (int rr = 0; rr < (PR + RPP - 1) / RPP; ++rr) {
+        const int p = r0 + rr * RPP, pq = tile * PR + p;
+        if (p >= PR || pq >= a.npool) continue;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = Ct[4 * p][chunk * 8 + e];
+#pragma unroll
+        for (int k = 1; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], Ct[4 * p + k][chunk * 8 + e]);
+        half8_t hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(v[e], h, l); hi[e] = h; lo[e] = l; }
+        const int b = pq / OHW, r = pq - b * OHW, oy = r / OW, ox = r - oy * OW;
+        _Float16 *o = out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + ox) * a.Cp_out + a.out_ch_off + ch0;
+        *reinterpret_cast<half8_t *>(o) = hi;
+        *reinterpret_cast<half8_t *>(o + a.split_n) = lo;
+        *reinterpret_cast<half8_t *>(o + 2 * a.split_n) = hi;
     }
 }
 
@@ -360,7 +403,7 @@ __device__ __forceinline__ void lds_dma16(const char *base, unsigned off, _Float
     __builtin_amdgcn_global_load_lds((glb_void_t *)(base + off), (lds_void_t *)lds, 16, 0, 0);
 }
 
-template <int BN>
+template <int BN, bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                         float *__restrict__ out_f32, const ConvF16Args a)
@@ -369,7 +412,8 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
     constexpr int WN = BN / 64, WM = 4 / WN, MT = BM / WM / 32;
     constexpr int AG = BM / 8 / 4, BG = BN / 8 / 4;        // 8-row groups per wavefront for A and B
     constexpr int kStageHalves = 2 * BM * ROWH + 2 * BN * ROWH;
-    constexpr int kEpiHalves = BM * kCtRow;
+    constexpr int kCtF = 64 + 4;                           // floats per row of the split mode's fp32 epilogue tile (64 columns per pass)
+    constexpr int kEpiHalves = SPLIT ? BM * kCtF * 2 : BM * kCtRow;
     constexpr int kArena = kStageHalves > kEpiHalves ? kStageHalves : kEpiHalves;
     __shared__ __attribute__((aligned(1024))) _Float16 smem[kArena + 2 * BM];   // + fo table (BM ints) at the end
     int *fo_s = reinterpret_cast<int *>(smem + kArena);
@@ -487,6 +531,53 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
         }
         return;
     }
+    if constexpr (SPLIT) {
+        // fp32 tile (bias + leaky in fp32, nothing rounded yet), 64 columns per pass (the whole 128 x 128 fp32 tile would not fit the
+        // static LDS limit), then per 8 channels: pool (if fused), split into (hi, lo), three stores
+        float (*Cf)[kCtF] = reinterpret_cast<float (*)[kCtF]>(smem);
+#pragma unroll
+        for (int hcol = 0; hcol < WN; ++hcol) {
+            if (hcol) __syncthreads();       // the previous pass's tile has been read
+            if (wn == hcol) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = j * 32 + (lane & 31);
+                    const float bv = bias[n0 + hcol * 64 + col];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = wm * (32 * MT) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            float v = acc[i][j][r] + bv;
+                            if (a.leaky && v < 0.f) v *= 0.1f;
+                            Cf[row][col] = v;
+                        }
+                }
+            }
+            __syncthreads();
+            if (a.pool) {
+                store_pooled_split<BM, 64, 256, kCtF>(Cf, out, a, tile, n0 + hcol * 64, tid);
+                continue;
+            }
+            constexpr int CH = 8, ROWS_PER_PASS = 256 / CH;
+            const int chunk = tid % CH, r0 = tid / CH, ch0 = n0 + hcol * 64 + chunk * 8;
+            if (ch0 < a.n_store) {
+#pragma unroll
+                for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
+                    const int row = r0 + rr * ROWS_PER_PASS;
+                    if (q0 + row >= a.npix) continue;
+                    half8_t hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { _Float16 h, l; split_f32(Cf[row][chunk * 8 + e], h, l); hi[e] = h; lo[e] = l; }
+                    _Float16 *o = out + ((size_t)kLead + fo_s[row]) * a.Cp_out + a.out_ch_off + ch0;
+                    *reinterpret_cast<half8_t *>(o) = hi;
+                    *reinterpret_cast<half8_t *>(o + a.split_n) = lo;
+                    *reinterpret_cast<half8_t *>(o + 2 * a.split_n) = hi;
+                }
+            }
+        }
+        return;
+    }
     _Float16 (*Ct)[kCtRow] = reinterpret_cast<_Float16 (*)[kCtRow]>(smem);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -535,7 +626,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
 // straddled an image-row end its rows skipped one and 39 % of the LDS cycles were bank conflicts.)
 // A dense tile has no zeros for out-of-image taps, so a lane whose tap leaves the image reads a
 // dedicated all-zero row instead (one v_cndmask on the address; identical addresses broadcast).
-template <int BN, int NB, int NW = 8, int TS = 32>
+template <int BN, int NB, int NW = 8, int TS = 32, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                         const ConvF16Args a, const int lt_rows)
@@ -759,29 +850,44 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 #pragma unroll
     for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) fo_r[rr] = fo_s[r0 + rr * ROWS_PER_PASS];
     __syncthreads();
+    // split mode: two passes through the same fp16 tile - the hi halves (stored to parts 0 and 2 of the item), then the lo halves (part 1)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int col = wn * 64 + j * TS + frow;
-        const float bv = bias[n0 + col];
+    for (int pass = 0; pass < (SPLIT ? 2 : 1); ++pass) {
+        if (pass) __syncthreads();           // the hi tile has been read
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int j = 0; j < NJ; ++j) {
+            const int col = wn * 64 + j * TS + frow;
+            const float bv = bias[n0 + col];
 #pragma unroll
-            for (int r = 0; r < (TS == 32 ? 16 : 4); ++r) {
-                // D layout: 32x32: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); 16x16: row = r + 4 (lane >> 4); column = lane % TS
-                const int row = wm * (TS * MT) + i * TS + (TS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fhalf : r + 4 * fhalf);
-                float v = acc[i][j][r] + bv;
-                if (a.leaky && v < 0.f) v *= 0.1f;
-                Ct[row][col] = (_Float16)v;
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < (TS == 32 ? 16 : 4); ++r) {
+                    // D layout: 32x32: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5); 16x16: row = r + 4 (lane >> 4); column = lane % TS
+                    const int row = wm * (TS * MT) + i * TS + (TS == 32 ? (r & 3) + 8 * (r >> 2) + 4 * fhalf : r + 4 * fhalf);
+                    float v = acc[i][j][r] + bv;
+                    if (a.leaky && v < 0.f) v *= 0.1f;
+                    if constexpr (SPLIT) {
+                        _Float16 h, l;
+                        split_f32(v, h, l);
+                        Ct[row][col] = pass ? l : h;
+                    } else
+                        Ct[row][col] = (_Float16)v;
+                }
+        }
+        __syncthreads();
+        if (ch0 < a.n_store) {
+#pragma unroll
+            for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
+                const int row = r0 + rr * ROWS_PER_PASS;
+                if (q0 + row >= a.npix) continue;
+                const half8_t v = *reinterpret_cast<const half8_t *>(&Ct[row][chunk * 8]);
+                _Float16 *o = out + ((size_t)kLead + fo_r[rr]) * a.Cp_out + a.out_ch_off + ch0;
+                if constexpr (SPLIT) {
+                    if (pass == 0) { *reinterpret_cast<half8_t *>(o) = v; *reinterpret_cast<half8_t *>(o + 2 * a.split_n) = v; }
+                    else *reinterpret_cast<half8_t *>(o + a.split_n) = v;
+                } else
+                    *reinterpret_cast<half8_t *>(o) = v;
             }
-    }
-    __syncthreads();
-    if (ch0 < a.n_store) {
-#pragma unroll
-        for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
-            const int row = r0 + rr * ROWS_PER_PASS;
-            if (q0 + row >= a.npix) continue;
-            const half8_t v = *reinterpret_cast<const half8_t *>(&Ct[row][chunk * 8]);
-            *reinterpret_cast<half8_t *>(out + ((size_t)kLead + fo_r[rr]) * a.Cp_out + a.out_ch_off + ch0) = v;
         }
     }
 #ifdef Y2_STAMPS
@@ -800,7 +906,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
 // last chunk, its first weight tile during this tile's last tap, and the epilogue needs no LDS (operands swapped: a lane
 // ends up with 4 consecutive channels of a pixel, see k_gemm1_f16_p), so the next tile's MFMAs start while the stores
 // drain.  Same dense input tile, swizzle and zero-row masking as k_conv_f16_halo.  NB = 2.
-template <int BN, int NW, int TS>
+template <int BN, int NW, int TS, bool SPLIT = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                           const float *__restrict__ bias, _Float16 *__restrict__ out,
                                                           const ConvF16Args a, const int lt_rows, const int n_tile_total)
@@ -1017,6 +1123,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__r
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 unsigned pk[NR / 4][2];
+                unsigned pkl[SPLIT ? NR / 4 : 1][2];
 #pragma unroll
                 for (int g = 0; g < NR / 4; ++g) {
                     float v0 = acc[i][j][4 * g + 0] + bv[g].x, v1 = acc[i][j][4 * g + 1] + bv[g].y;
@@ -1028,6 +1135,12 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__r
                     const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
                     pk[g][0] = __builtin_bit_cast(unsigned, h01);
                     pk[g][1] = __builtin_bit_cast(unsigned, h23);
+                    if constexpr (SPLIT) {       // the lo halves of the same four values
+                        const half2_t l01 = {(_Float16)(v0 - (float)h01[0]), (_Float16)(v1 - (float)h01[1])};
+                        const half2_t l23 = {(_Float16)(v2 - (float)h23[0]), (_Float16)(v3 - (float)h23[1])};
+                        pkl[g][0] = __builtin_bit_cast(unsigned, l01);
+                        pkl[g][1] = __builtin_bit_cast(unsigned, l23);
+                    }
                 }
                 if constexpr (TS == 32) {        // pair the lane halves' groups: 8 consecutive channels = 16 bytes per lane
 #pragma unroll
@@ -1036,11 +1149,26 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__r
                         const uint2v s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
                         const uint2v s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
                         const int c0 = cb + 8 * (2 * pr + fhe);
-                        if (qok[i] && c0 < a.n_store) *reinterpret_cast<uint4 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        if (qok[i] && c0 < a.n_store) {
+                            *reinterpret_cast<uint4 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                            if constexpr (SPLIT) *reinterpret_cast<uint4 *>(obase + (orow[i] + (unsigned)((c0 + 2 * a.split_n) * 2))) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                        }
+                        if constexpr (SPLIT) {
+                            const uint2v t0 = __builtin_amdgcn_permlane32_swap(pkl[2 * pr][0], pkl[2 * pr + 1][0], false, false);
+                            const uint2v t1 = __builtin_amdgcn_permlane32_swap(pkl[2 * pr][1], pkl[2 * pr + 1][1], false, false);
+                            if (qok[i] && c0 < a.n_store)
+                                *reinterpret_cast<uint4 *>(obase + (orow[i] + (unsigned)((c0 + a.split_n) * 2))) = make_uint4(t0[0], t1[0], t0[1], t1[1]);
+                        }
                     }
                 } else {
                     const int c0 = cb + 4 * fhe;
-                    if (qok[i] && c0 < a.n_store) *reinterpret_cast<uint2 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint2(pk[0][0], pk[0][1]);
+                    if (qok[i] && c0 < a.n_store) {
+                        *reinterpret_cast<uint2 *>(obase + (orow[i] + (unsigned)(c0 * 2))) = make_uint2(pk[0][0], pk[0][1]);
+                        if constexpr (SPLIT) {
+                            *reinterpret_cast<uint2 *>(obase + (orow[i] + (unsigned)((c0 + 2 * a.split_n) * 2))) = make_uint2(pk[0][0], pk[0][1]);
+                            *reinterpret_cast<uint2 *>(obase + (orow[i] + (unsigned)((c0 + a.split_n) * 2))) = make_uint2(pkl[0][0], pkl[0][1]);
+                        }
+                    }
                 }
             }
         }
@@ -1386,6 +1514,9 @@ __global__ __launch_bounds__(256) void k_conv_f16_c32_pool(const _Float16 *__res
 // = 64 fp32 accumulators; the 27x32 weights are read from LDS as broadcast 16-byte reads;
 // output = layer-1 items (32 halves).
 // w0: [27][32] fp32 (k = c*9 + i*3 + j), bias0: [32] fp32.
+// SPLIT (fp32tol mode): nothing is rounded to fp16 before the pool; the pooled fp32 value leaves as (hi, lo) in an item of 128 halves
+// [hi 32 | lo 32 | hi 32 | 32 zero].
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restrict__ frames, const float *__restrict__ w0,
                                                          const float *__restrict__ bias0, _Float16 *__restrict__ out,
                                                          int B, int H, int W, int oWp, int oPL)
@@ -1457,10 +1588,10 @@ __global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restri
             for (int n4 = 0; n4 < 4; ++n4) wcur[n4] = wnxt[n4];
         }
     }
-    half8_t *dst = reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + nh);
+    half8_t *dst = reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * (SPLIT ? 128 : 32) + nh);
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        half8_t o;
+        half8_t o, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int n = k * 8 + e;
@@ -1470,12 +1601,84 @@ __global__ __launch_bounds__(256, 2) void k_conv0_pool_f16(const float *__restri
                 float v = acc[p][n];
                 v = v < 0.f ? v * 0.1f : v;          // leaky, then pool (same order as the layer pipeline)
                 // the layer-0 tensor is fp16 in the unfused pipeline: round before the max like it does
-                m = fmaxf(m, (float)(_Float16)v);
+                m = fmaxf(m, SPLIT ? v : (float)(_Float16)v);
             }
-            o[e] = (_Float16)m;
+            if constexpr (SPLIT) { _Float16 h, l; split_f32(m, h, l); o[e] = h; ol[e] = l; }
+            else o[e] = (_Float16)m;
         }
         dst[k] = o;
+        if constexpr (SPLIT) { dst[k + 4] = ol; dst[k + 8] = o; }     // parts at +32 and +64 halves
     }
+}
+
+// ------------------------------------------------------------------ split-fp16 ("fp32tol") helpers
+
+// 2x2/2 max pool on split items [hi | lo | hi] of PS channels per part: the max of the fp32 values hi + lo (an exact sum), whose
+// own (hi, lo) pair is copied.  One thread per (output pixel, 8-channel chunk of a part).
+__global__ void k_maxpool2_split(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int PS, int Cp, int B, int OH, int OW,
+                                 int iWp, int iPL, int oWp, int oPL)
+{
+    const int chunks = PS / 8;
+    const long n = (long)B * OH * OW * chunks;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int ck = (int)(t % chunks);
+    const long p = t / chunks;
+    const int x = (int)(p % OW), y = (int)((p / OW) % OH), b = (int)(p / ((long)OW * OH));
+    const size_t s = ((size_t)kLead + (size_t)b * iPL + (size_t)(2 * y + 1) * iWp + 2 * x) * Cp + ck * 8;
+    const size_t offs[4] = {0, (size_t)Cp, (size_t)iWp * Cp, (size_t)iWp * Cp + Cp};
+    half8_t bh = *reinterpret_cast<const half8_t *>(in + s), bl = *reinterpret_cast<const half8_t *>(in + s + PS);
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const half8_t h = *reinterpret_cast<const half8_t *>(in + s + offs[k]), l = *reinterpret_cast<const half8_t *>(in + s + offs[k] + PS);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if ((float)h[e] + (float)l[e] > (float)bh[e] + (float)bl[e]) { bh[e] = h[e]; bl[e] = l[e]; }
+    }
+    _Float16 *o = out + ((size_t)kLead + (size_t)b * oPL + (size_t)(y + 1) * oWp + x) * Cp + ck * 8;
+    *reinterpret_cast<half8_t *>(o) = bh;
+    *reinterpret_cast<half8_t *>(o + PS) = bl;
+    *reinterpret_cast<half8_t *>(o + 2 * PS) = bh;
+}
+
+// Darknet legacy reorg on split items: part p of the 64-channel input goes to channels [0, 256) of part p of the concat items
+__global__ void k_reorg_split(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int B, int iPS, int iCp, int iWp, int iPL,
+                              int oPS, int oCp, int oWp, int oPL)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * 256 * 169) return;
+    const int b = t / (256 * 169), o = t - b * (256 * 169);
+    const int k = o / (26 * 416), rem = o - k * (26 * 416), j = rem / 26, i = rem - j * 26;
+    const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));
+    const int sc = sidx / 676, sr = sidx - sc * 676, sy = sr / 26, sx = sr - sy * 26;
+    const int oc = o / 169, orr = o - oc * 169, oy = orr / 13, ox = orr - oy * 13;
+    const _Float16 *src = in + ((size_t)kLead + (size_t)b * iPL + (size_t)(sy + 1) * iWp + sx) * iCp + sc;
+    _Float16 *dst = out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * oCp + oc;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) dst[p * oPS] = src[p * iPS];
+}
+
+// weights_reorg (fp32 stream of one layer) -> wh[N_pad][KK][Cp] halves for the split mode: Cp = three parts of PS channels
+// (+ zero padding), part 0 and part 1 hold w_hi = fp16(w), part 2 holds w_lo = fp16(w - w_hi): against activations [a_hi | a_lo | a_hi].
+__global__ void k_pack_weights_split(const float *__restrict__ src, _Float16 *__restrict__ dst, float *__restrict__ bias_dst,
+                                     const float *__restrict__ bias_src, int C, int N, int KK, int PS, int Cp, int Npad)
+{
+    const long n = (long)Npad * KK * Cp;
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < Npad) bias_dst[t] = t < N ? bias_src[t] : 0.f;
+    if (t >= n) return;
+    const int cc = (int)(t % Cp), part = cc / PS, ci = cc - part * PS;
+    const int tap = (int)((t / Cp) % KK);
+    const int m = (int)(t / ((long)Cp * KK));
+    float v = 0.f;
+    if (m < N && ci < C && part < 3) {
+        const int m0 = m / kTm * kTm, tm = m - m0, tm_min = min(kTm, N - m0);
+        const int n0 = ci / kTn * kTn, tn = ci - n0, tn_min = min(kTn, C - n0);
+        v = src[(long)m0 * C * KK + (long)tm_min * n0 * KK + (long)tap * tm_min * tn_min + tm * tn_min + tn];
+    }
+    _Float16 h, l;
+    split_f32(v, h, l);
+    dst[t] = part == 2 ? l : h;
 }
 
 // ------------------------------------------------------------------ small fp16 kernels

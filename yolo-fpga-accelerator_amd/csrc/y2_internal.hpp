@@ -248,6 +248,12 @@ struct yolo2_hip_ctx {
         _Float16 *d = nullptr;
     };
     bool f16_loaded = false;
+    // split-fp16 ("fp32tol") mode: a twin context that runs the fp16 launch table on items of three parts [hi | lo | hi] with
+    // weights packed [w_hi | w_hi | w_lo] (kernels_f16.hpp, SPLIT instantiations).  The twin owns its packed weights (wh / biasf), its
+    // tensors, table and lanes; it borrows the fp32 blobs and w0f from this context.
+    bool split = false;                // this context IS such a twin (or a lane of one)
+    bool borrows_f32 = false;          // w0f / wf32 / bf32 belong to the parent
+    yolo2_hip_ctx *tol = nullptr;      // the parent's twin, made at the first yolo2_hip_run_batch_f32tol
     _Float16 *wh = nullptr;
     float *biasf = nullptr;
     float *w0f = nullptr;  // layer 0: [27][32] fp32 weights + [32] bias for the fused conv0+pool kernel

@@ -68,8 +68,8 @@ struct F16Step {
     const float *bias = nullptr, *w0 = nullptr;
     _Float16 *out = nullptr;
     int B = 0;
-    // pool / reorg steps: source and destination geometry
-    int iCp = 0, iWp = 0, iPL = 0, oCp = 0, oWp = 0, oPL = 0, OH = 0, OW = 0;
+    // pool / reorg steps: source and destination geometry (iPS / oPS: part strides of split items)
+    int iCp = 0, iWp = 0, iPL = 0, oCp = 0, oWp = 0, oPL = 0, OH = 0, OW = 0, iPS = 0, oPS = 0;
 };
 
 struct F16Plan {
@@ -95,7 +95,7 @@ void y2_f16_plan_free(yolo2_hip_ctx *c)
 #endif
 
 static int f16_store_check(const char *kernel, int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store,
-                           int oWp, int oPL, int npix, int npool, int dst_B, int dst_H, int dst_W, int dst_Cp)
+                           int oWp, int oPL, int npix, int npool, int dst_B, int dst_H, int dst_W, int dst_Cp, int split_n = 0)
 {
     if (store == FS_REGION) return YOLO2_SUCCESS;
     const bool pooled = store == FS_POOL_ONLY || (store == FS_FULL_OR_POOL && pool);
@@ -111,6 +111,10 @@ static int f16_store_check(const char *kernel, int store, int pool, int B, int H
     if (Cp_out != dst_Cp || out_ch_off < 0 || n_store < 0 || out_ch_off + n_store > dst_Cp)
         return fail(YOLO2_ERROR, "fp16 plan: %s stores channels [%d, %d) of %d-channel items into %d-channel items", kernel, out_ch_off,
                     out_ch_off + n_store, Cp_out, dst_Cp);
+    // split mode: the same channel window in each of the three parts [hi | lo | hi] of split_n channels
+    if (split_n && (split_n < out_ch_off + n_store || 2 * split_n + out_ch_off + n_store > dst_Cp))
+        return fail(YOLO2_ERROR, "fp16 plan (split): %s stores channels [%d, %d) of three parts of %d channels into %d-channel items", kernel,
+                    out_ch_off, out_ch_off + n_store, split_n, dst_Cp);
     return YOLO2_SUCCESS;
 }
 
@@ -140,12 +144,15 @@ extern "C" int yolo2_hip_load_weights_fp32_dev(yolo2_hip_ctx *c, uint64_t weight
                             hipMemcpyDeviceToDevice);
 }
 
-static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind)
+// Item size (halves) of a tensor of C channels: plain fp16 items are C rounded up to 32; split items ("fp32tol" mode) are three parts
+// [hi | lo | hi] of PS = C rounded up to 32 channels each, the whole rounded up to the 64-channel K-step of the LDS-DMA kernels.
+static inline int part_stride(int C) { return round_up(C, 32); }
+static inline int item_halves(int C, bool split) { return split ? round_up(3 * part_stride(C), 64) : part_stride(C); }
+
+// Packs the fp32 blobs (device, reference stream order) into this context's fp16 weight layout: [N_pad][tap][Cp] halves, plain or
+// split ([w_hi | w_hi | w_lo] against activations [a_hi | a_lo | a_hi]).  Replaces c->wh / c->biasf and resets the launch table.
+static int pack_half_weights(yolo2_hip_ctx *c, const float *wd, const float *bd)
 {
-    if (!c || !weights_reorg || !bias) return fail(YOLO2_ERROR, "null argument");
-    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
-    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
-    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
     long wtot = 0, btot = 0;
     int ord = 0;
     for (int i = 0; i < 32; ++i)
@@ -154,7 +161,7 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
             const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN);
             c->wh_off[ord] = wtot;
             c->biasf_off[ord] = btot;
-            wtot += i == 0 ? (long)npad * 32 : (long)npad * l.size * l.size * round_up(l.c, 32);
+            wtot += i == 0 ? (long)npad * 32 : (long)npad * l.size * l.size * item_halves(l.c, c->split);
             btot += npad;
             ord++;
         }
@@ -168,26 +175,48 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     if (c->biasf) (void)hipFree(c->biasf);
     c->wh = nullptr;
     c->biasf = nullptr;
-    float *wd = nullptr, *bd = nullptr;
     HIP_TRY(hipMalloc((void **)&c->wh, (size_t)wtot * 2), YOLO2_MMAP_ERROR);
     HIP_TRY(hipMalloc((void **)&c->biasf, (size_t)btot * 4), YOLO2_MMAP_ERROR);
-    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 4), YOLO2_MMAP_ERROR);
-    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 4), YOLO2_MMAP_ERROR);
-    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, kind), YOLO2_DMA_ERROR);
-    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, kind), YOLO2_DMA_ERROR);
     long woff = 0, boff = 0;
     ord = 0;
     for (int i = 0; i < 32; ++i) {
         const LayerDesc &l = kNet[i];
         if (l.type != L_CONV) continue;
         const int npad = round_up(l.n, l.n <= 64 ? 64 : kBN), KK = l.size * l.size;
-        const int Cp = i == 0 ? 32 : round_up(l.c, 32);
-        const long n = (long)npad * (i == 0 ? 1 : KK) * Cp;
-        hipLaunchKernelGGL(k_pack_weights_f16, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
-                           c->wh + c->wh_off[ord], c->biasf + c->biasf_off[ord], bd + boff, l.c, l.n, KK, Cp, npad, i == 0 ? 1 : 0);
+        if (c->split && i > 0) {
+            const int Cp = item_halves(l.c, true);
+            const long n = (long)npad * KK * Cp;
+            hipLaunchKernelGGL(k_pack_weights_split, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
+                               c->wh + c->wh_off[ord], c->biasf + c->biasf_off[ord], bd + boff, l.c, l.n, KK, part_stride(l.c), Cp, npad);
+        } else {
+            const int Cp = i == 0 ? 32 : round_up(l.c, 32);
+            const long n = (long)npad * (i == 0 ? 1 : KK) * Cp;
+            hipLaunchKernelGGL(k_pack_weights_f16, dim3(blocks_for(std::max<long>(n, npad), 256)), dim3(256), 0, nullptr, wd + woff,
+                               c->wh + c->wh_off[ord], c->biasf + c->biasf_off[ord], bd + boff, l.c, l.n, KK, Cp, npad, i == 0 ? 1 : 0);
+        }
         woff += yolo2_weight_len[ord];
         boff += yolo2_bias_len[ord];
         ord++;
+    }
+    HIP_TRY(hipGetLastError(), YOLO2_ERROR);
+    return YOLO2_SUCCESS;
+}
+
+static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t n_weights, const void *bias, size_t n_bias, hipMemcpyKind kind)
+{
+    if (!c || !weights_reorg || !bias) return fail(YOLO2_ERROR, "null argument");
+    if (n_weights < YOLO2_N_WEIGHTS) return fail(YOLO2_ERROR, "weights file too small");
+    if (n_bias < YOLO2_N_BIAS) return fail(YOLO2_ERROR, "bias file too small");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    if (c->tol) { yolo2_hip_destroy(c->tol); c->tol = nullptr; }   // the split-mode twin packs from the blobs that are about to be replaced
+    float *wd = nullptr, *bd = nullptr;
+    HIP_TRY(hipMalloc((void **)&wd, (size_t)YOLO2_N_WEIGHTS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&bd, (size_t)YOLO2_N_BIAS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(wd, weights_reorg, (size_t)YOLO2_N_WEIGHTS * 4, kind), YOLO2_DMA_ERROR);
+    HIP_TRY(hipMemcpy(bd, bias, (size_t)YOLO2_N_BIAS * 4, kind), YOLO2_DMA_ERROR);
+    {
+        const int prc = pack_half_weights(c, wd, bd);
+        if (prc) return prc;
     }
     // the halo-tile kernels use up to the whole 160 KiB of LDS: raise their dynamic-LDS limit on THIS device
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
@@ -198,6 +227,10 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<128, 3, 8, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
@@ -231,13 +264,13 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
     y2_free_f16_activations(c);
     if (c->f16_plan) { c->f16_plan->batch = 0; c->f16_plan->steps.clear(); }   // the table points into the tensors just freed
     int rc;
-    if ((rc = alloc_half(c->h_cat, 1280, 1280, 13, 13, B))) return rc;
+    if ((rc = alloc_half(c->h_cat, 1280, item_halves(1280, c->split), 13, 13, B))) return rc;
     for (int i = 1; i < 30; ++i) {   // layer 0's 416x416x32 tensor never exists: conv0+pool are fused
         const LayerDesc &l = kNet[i];
         if (l.type == L_CONV && i != 24) {
-            if ((rc = alloc_half(c->h_out[i], l.n, round_up(l.n, 32), l.h, l.w, B))) return rc;
+            if ((rc = alloc_half(c->h_out[i], l.n, item_halves(l.n, c->split), l.h, l.w, B))) return rc;
         } else if (l.type == L_MAX) {
-            if ((rc = alloc_half(c->h_out[i], l.c, round_up(l.c, 32), l.h / 2, l.w / 2, B))) return rc;
+            if ((rc = alloc_half(c->h_out[i], l.c, item_halves(l.c, c->split), l.h / 2, l.w / 2, B))) return rc;
         }
     }
     c->h_out[24] = c->h_cat;
@@ -257,18 +290,20 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
         __VA_ARGS__;                                                                                   \
     }
 Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL, s.T))
-Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
+template <bool SP> Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16<SP>, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
 template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
 Y2_LAUNCHER(L_c32_pool, hipLaunchKernelGGL(k_conv_f16_c32_pool, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.T))
-template <int BN> Y2_LAUNCHER(L_glds, hipLaunchKernelGGL((k_conv_f16_glds<BN>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
-                                                            s.store == FS_REGION ? region : (float *)nullptr, s.a))
+template <int BN, bool SP = false> Y2_LAUNCHER(L_glds, hipLaunchKernelGGL((k_conv_f16_glds<BN, SP>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
+                                                                            s.store == FS_REGION ? region : (float *)nullptr, s.a))
 template <int BN, int BK> Y2_LAUNCHER(L_reg, hipLaunchKernelGGL((k_conv_f16<128, BN, BK>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
                                                                    s.store == FS_REGION ? region : (float *)nullptr, s.a))
-template <int BN, int NW, int TS> Y2_LAUNCHER(L_halo_p, hipLaunchKernelGGL((k_conv_f16_halo_p<BN, NW, TS>), s.grid, s.block, s.lds, st, s.in, s.w,
-                                                                            s.bias, s.out, s.a, s.lt_rows, s.T))
-template <int BN, int NB, int NW, int TS> Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS>), s.grid, s.block, s.lds, st, s.in,
-                                                                                  s.w, s.bias, s.out, s.a, s.lt_rows))
+template <int BN, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo_p, hipLaunchKernelGGL((k_conv_f16_halo_p<BN, NW, TS, SP>), s.grid, s.block, s.lds, st, s.in, s.w,
+                                                                                            s.bias, s.out, s.a, s.lt_rows, s.T))
+template <int BN, int NB, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS, SP>), s.grid, s.block, s.lds, st, s.in,
+                                                                                                  s.w, s.bias, s.out, s.a, s.lt_rows))
+Y2_LAUNCHER(L_maxpool_split, hipLaunchKernelGGL(k_maxpool2_split, s.grid, s.block, 0, st, s.in, s.out, s.oPS, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
+Y2_LAUNCHER(L_reorg_split, hipLaunchKernelGGL(k_reorg_split, s.grid, s.block, 0, st, s.in, s.out, s.B, s.iPS, s.iCp, s.iWp, s.iPL, s.oPS, s.oCp, s.oWp, s.oPL))
 Y2_LAUNCHER(L_maxpool, hipLaunchKernelGGL(k_maxpool2_f16, s.grid, s.block, 0, st, s.in, s.out, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
 Y2_LAUNCHER(L_reorg, hipLaunchKernelGGL(k_reorg_f16, s.grid, s.block, 0, st, s.in, s.out, s.B, s.iCp, s.iWp, s.iPL, s.oCp, s.oWp, s.oPL))
 #undef Y2_LAUNCHER
@@ -282,9 +317,10 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
     P.steps.clear();
     P.batch = 0;
     typedef yolo2_hip_ctx::HalfTensor HT;
+    const bool split = c->split;     // "fp32tol" mode: items of three parts [hi | lo | hi], SPLIT kernel instantiations
     auto checked_push = [&](F16Step &s, const HT &dst) -> int {
         const int rc = f16_store_check(s.kernel, s.store, s.a.pool, B, s.a.H, s.a.W, s.a.Cp_out, s.a.out_ch_off, s.a.n_store, s.a.oWp, s.a.oPL,
-                                       s.a.npix, s.a.npool, dst.B, dst.H, dst.W, dst.Cp);
+                                       s.a.npix, s.a.npool, dst.B, dst.H, dst.W, dst.Cp, s.store == FS_REGION ? 0 : s.a.split_n);
         if (rc) return rc;
         P.steps.push_back(s);
         return YOLO2_SUCCESS;
@@ -295,15 +331,18 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         s.layer = 0; s.B = B;   // (booked to layer 0; the pool, layer 1, has no launch of its own)
         s.w0 = c->w0f; s.bias = c->w0f + 27 * 32; s.out = g.d; s.oWp = g.Wp; s.oPL = g.PL;
         s.block = dim3(256);
-        if (!sw.no_mfma0) {   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
+        if (split) {          // fp32 VALU form, nothing rounded before the pool, (hi, lo) out: 128-halve items
+            s.kernel = "k_conv0_pool_f16<split>"; s.launch = L_conv0_valu<true>;
+            s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
+        } else if (!sw.no_mfma0) {   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
             s.kernel = "k_conv0_pool_mfma"; s.launch = L_conv0_mfma;
             s.T = B * (416 / 16) * (416 / 32);
             s.grid = dim3((unsigned)std::min(s.T, 256 * Y2_CONV0_WGS));   // persistent workgroups, Y2_CONV0_WGS per CU
         } else {
-            s.kernel = "k_conv0_pool_f16"; s.launch = L_conv0_valu;
+            s.kernel = "k_conv0_pool_f16"; s.launch = L_conv0_valu<false>;
             s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
         }
-        if (g.B != B || g.H != 208 || g.W != 208 || g.Cp != 32) return fail(YOLO2_ERROR, "fp16 plan: layer-1 tensor has the wrong geometry");
+        if (g.B != B || g.H != 208 || g.W != 208 || g.Cp != (split ? 128 : 32)) return fail(YOLO2_ERROR, "fp16 plan: layer-1 tensor has the wrong geometry");
         P.steps.push_back(s);
     }
     int ord = 1, skip_pool = -1;
@@ -328,6 +367,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             a.KS = l.size;
             a.pool = 0; a.oWp = a.oPL = a.npool = 0;
             a.n_tiles = 1;
+            a.split_n = split && i != 30 ? part_stride(i == 24 ? 1280 : l.n) : 0;
             set_fast_div(a);
             a.stamp = sw.stamp_layer == i;
             s.w = (const _Float16 *)(c->wh + c->wh_off[ord]);
@@ -358,7 +398,8 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             int rc = YOLO2_SUCCESS;
             bool done = false;
             // 1x1 layers: persistent workgroups over a ring of staged K-steps (k_gemm1_f16_p)
-            if (!done && l.size == 1 && bk64 && (i == 30 || sw.ring_all) && in32 && !sw.no_ring) {
+            if (split && !bk64) return fail(YOLO2_ERROR, "fp16 plan (split): layer %d has %d-channel items, not a multiple of the 64-channel K-step", i, a.Cp_in);
+            if (!done && l.size == 1 && bk64 && (i == 30 || (sw.ring_all && !split)) && in32 && !sw.no_ring) {
                 const int bn = l.n <= 64 ? 64 : 128;
                 a.n_tiles = round_up(l.n, bn) / bn;
                 s.T = ((a.npix + 255) / 256) * a.n_tiles;
@@ -381,7 +422,8 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             if (!done && l.n <= 64) {
                 a.n_tiles = round_up(l.n, 64) / 64;
                 s.grid = dim3(m_tiles * a.n_tiles); s.block = dim3(256);
-                if (glds) { s.kernel = "k_conv_f16_glds<64>"; s.launch = L_glds<64>; }
+                if (split) { s.kernel = "k_conv_f16_glds<64,split>"; s.launch = L_glds<64, true>; }
+                else if (glds) { s.kernel = "k_conv_f16_glds<64>"; s.launch = L_glds<64>; }
                 else if (bk64) { s.kernel = "k_conv_f16<128,64,64>"; s.launch = L_reg<64, 64>; }
                 else { s.kernel = "k_conv_f16<128,64,32>"; s.launch = L_reg<64, 32>; }
                 done = true;
@@ -405,7 +447,9 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                         //  differ from k_conv_f16_halo - it measured 2.8 % slower over the pass at batch 256.)
                         s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8))));
                         s.lds = (unsigned)lds; s.lt_rows = lt_rows; s.store = FS_FULL;
-                        if (wide && sw.m16) { s.kernel = "k_conv_f16_halo_p<256,16,16>"; s.launch = L_halo_p<256, 16, 16>; s.block = dim3(1024); }
+                        if (split && wide) { s.kernel = "k_conv_f16_halo_p<256,16,32,split>"; s.launch = L_halo_p<256, 16, 32, true>; s.block = dim3(1024); }
+                        else if (split) { s.kernel = "k_conv_f16_halo_p<128,8,32,split>"; s.launch = L_halo_p<128, 8, 32, true>; s.block = dim3(512); }
+                        else if (wide && sw.m16) { s.kernel = "k_conv_f16_halo_p<256,16,16>"; s.launch = L_halo_p<256, 16, 16>; s.block = dim3(1024); }
                         else if (wide) { s.kernel = "k_conv_f16_halo_p<256,16,32>"; s.launch = L_halo_p<256, 16, 32>; s.block = dim3(1024); }
                         else if (sw.m16) { s.kernel = "k_conv_f16_halo_p<128,8,16>"; s.launch = L_halo_p<128, 8, 16>; s.block = dim3(512); }
                         else { s.kernel = "k_conv_f16_halo_p<128,8,32>"; s.launch = L_halo_p<128, 8, 32>; s.block = dim3(512); }
@@ -427,12 +471,15 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                         if (wide) {
                             a.n_tiles = l.n / 256;
                             s.grid = dim3(((a.npix + 255) / 256) * a.n_tiles); s.lds = (unsigned)lds256;
-                            if (sw.m16) { s.kernel = "k_conv_f16_halo<256,2,16,16>"; s.launch = L_halo<256, 2, 16, 16>; s.block = dim3(1024); }
+                            if (split) { s.kernel = "k_conv_f16_halo<256,2,16,32,split>"; s.launch = L_halo<256, 2, 16, 32, true>; s.block = dim3(1024); }
+                            else if (sw.m16) { s.kernel = "k_conv_f16_halo<256,2,16,16>"; s.launch = L_halo<256, 2, 16, 16>; s.block = dim3(1024); }
                             else if (!sw.w8) { s.kernel = "k_conv_f16_halo<256,2,16>"; s.launch = L_halo<256, 2, 16, 32>; s.block = dim3(1024); }   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
                             else { s.kernel = "k_conv_f16_halo<256,2>"; s.launch = L_halo<256, 2, 8, 32>; s.block = dim3(512); }
                         } else {   // `fits` without `wide` implies `three`
                             s.grid = dim3(((a.npix + 255) / 256) * a.n_tiles); s.lds = (unsigned)lds128;
-                            s.kernel = "k_conv_f16_halo<128,3>"; s.launch = L_halo<128, 3, 8, 32>; s.block = dim3(512);
+                            if (split) { s.kernel = "k_conv_f16_halo<128,3,8,32,split>"; s.launch = L_halo<128, 3, 8, 32, true>; }
+                            else { s.kernel = "k_conv_f16_halo<128,3>"; s.launch = L_halo<128, 3, 8, 32>; }
+                            s.block = dim3(512);
                         }
                         done = true;
                     }
@@ -441,7 +488,8 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                 //  with two workgroups per CU: without the halo reuse the bigger tile only adds barrier cost)
                 if (!done) {
                     s.grid = dim3(m_tiles * a.n_tiles); s.block = dim3(256);
-                    if (glds) { s.kernel = "k_conv_f16_glds<128>"; s.launch = L_glds<128>; }
+                    if (split) { s.kernel = "k_conv_f16_glds<128,split>"; s.launch = L_glds<128, true>; }
+                    else if (glds) { s.kernel = "k_conv_f16_glds<128>"; s.launch = L_glds<128>; }
                     else if (bk64) { s.kernel = "k_conv_f16<128,128,64>"; s.launch = L_reg<128, 64>; }
                     else { s.kernel = "k_conv_f16<128,128,32>"; s.launch = L_reg<128, 32>; }
                     done = true;
@@ -460,6 +508,10 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             s.layer = i; s.B = B; s.kernel = "k_maxpool2_f16"; s.launch = L_maxpool;
             s.in = gi.d; s.out = go.d; s.oCp = go.Cp; s.OH = go.H; s.OW = go.W; s.iWp = gi.Wp; s.iPL = gi.PL; s.oWp = go.Wp; s.oPL = go.PL;
             s.grid = dim3(blocks_for((long)B * go.H * go.W * (go.Cp / 8), 256)); s.block = dim3(256);
+            if (split) {
+                s.kernel = "k_maxpool2_split"; s.launch = L_maxpool_split; s.oPS = part_stride(go.C);
+                s.grid = dim3(blocks_for((long)B * go.H * go.W * (s.oPS / 8), 256));
+            }
             P.steps.push_back(s);
             cur = &c->h_out[i];
             break;
@@ -471,6 +523,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             F16Step s;
             s.layer = i; s.B = B; s.kernel = "k_reorg_f16"; s.launch = L_reorg;
             s.in = gi.d; s.out = go.d; s.iCp = gi.Cp; s.iWp = gi.Wp; s.iPL = gi.PL; s.oCp = go.Cp; s.oWp = go.Wp; s.oPL = go.PL;
+            if (split) { s.kernel = "k_reorg_split"; s.launch = L_reorg_split; s.iPS = part_stride(gi.C); s.oPS = part_stride(go.C); }
             s.grid = dim3(blocks_for((long)B * 256 * 169, 256)); s.block = dim3(256);
             P.steps.push_back(s);
             cur = &c->h_cat;
@@ -525,6 +578,8 @@ static int make_f16_lanes(yolo2_hip_ctx *c, int want_lanes)
         made.push_back(l);
         l->device = c->device;
         l->is_lane = true;
+        l->opt = c->opt;
+        l->split = c->split;
         l->wh = c->wh; l->biasf = c->biasf; l->w0f = c->w0f;
         memcpy(l->wh_off, c->wh_off, sizeof(c->wh_off));
         memcpy(l->biasf_off, c->biasf_off, sizeof(c->biasf_off));
@@ -595,6 +650,71 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
     if (ev) c->prof_runs++;
     return YOLO2_SUCCESS;
 }
+
+// ---------------------------------------------------------------------------- split-fp16: the MFMA path inside the fp32 tolerance
+//
+// BASELINE.json's north star asks for the floating-point form "within 1e-3 box-coord tolerance for fp32" on the matrix cores.  The
+// plain fp16 path misses that (activations and weights rounded to 11 bits: max box-coordinate error 5.8e-3); the exact fp32 path
+// (yolo2_fp32.hip) is bit-identical but VALU-bound (1.4 k frames/s).  Here every fp32 value v travels as TWO halves,
+// hi = fp16(v) and lo = fp16(v - hi) (22 significant bits), and a product a w is taken as a_hi w_hi + a_lo w_hi + a_hi w_lo on
+// v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped a_lo w_lo term is 2^-22 relative).  No new contraction kernel: an
+// item holds three parts [a_hi | a_lo | a_hi], the weights are packed [w_hi | w_hi | w_lo], and the fp16 kernels contract over
+// the tripled channels as they are; only their epilogues differ (SPLIT instantiations: bias + leaky in fp32, then the (hi, lo)
+// split and three stores; pools take the max of the fp32 values).  Layer 0 runs its fp32 VALU form (k_conv0_pool_f16<true>: fp32
+// frames x fp32 weights).  The region layer's kernel writes fp32 as before.  3x the MFMA work and activation bytes of the fp16 path
+// for ~1e-6 relative error: reference arithmetic hls/core/core_compute.cpp:121-172 is what the result is within tolerance of.
+static int ensure_tol_twin(yolo2_hip_ctx *c)
+{
+    if (c->tol) return YOLO2_SUCCESS;
+    yolo2_hip_ctx *t = new (std::nothrow) yolo2_hip_ctx();
+    if (!t) return fail(YOLO2_ERROR, "out of host memory");
+    t->device = c->device;
+    t->opt = c->opt;
+    t->split = true;
+    t->borrows_f32 = true;
+    t->w0f = c->w0f; t->wf32 = c->wf32; t->bf32 = c->bf32;
+    int rc = pack_half_weights(t, c->wf32, c->bf32);
+    if (rc == YOLO2_SUCCESS && hipDeviceSynchronize() != hipSuccess) rc = fail(YOLO2_ERROR, "split weight packing failed");
+    if (rc) { yolo2_hip_destroy(t); return rc; }
+    t->f16_loaded = true;
+    if (c->prof) (void)yolo2_hip_set_profiling(t, 1);
+    c->tol = t;
+    return YOLO2_SUCCESS;
+}
+
+// Same contract as yolo2_hip_run_batch_fp16 (float frames in HBM -> dense fp32 region tensor [batch][425][13][13], enqueued on
+// `stream`), computed in the split representation.  Needs yolo2_hip_load_weights_fp32.
+extern "C" int yolo2_hip_run_batch_f32tol(yolo2_hip_ctx *c, uint64_t frames_dev, int batch, uint64_t region_dev, void *stream)
+{
+    if (!c) return fail(YOLO2_ERROR, "null ctx");
+    if (!c->f16_loaded || !c->wf32) return fail(YOLO2_ERROR, "fp32 weights not loaded (yolo2_hip_load_weights_fp32)");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    const int rc = ensure_tol_twin(c);
+    if (rc) return rc;
+    return yolo2_hip_run_batch_fp16(c->tol, frames_dev, batch, region_dev, stream);
+}
+
+extern "C" int yolo2_hip_run_batch_f32tol_host(yolo2_hip_ctx *c, const float *frames, int batch, float *region)
+{
+    if (!c || !frames || !region) return fail(YOLO2_ERROR, "null argument");
+    HIP_TRY(hipSetDevice(c->device), YOLO2_INIT_ERROR);
+    float *fd = nullptr, *rd = nullptr;
+    HIP_TRY(hipMalloc((void **)&fd, (size_t)batch * YOLO2_FRAME_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMalloc((void **)&rd, (size_t)batch * YOLO2_REGION_ELEMS * 4), YOLO2_MMAP_ERROR);
+    HIP_TRY(hipMemcpy(fd, frames, (size_t)batch * YOLO2_FRAME_ELEMS * 4, hipMemcpyHostToDevice), YOLO2_DMA_ERROR);
+    int rc = yolo2_hip_run_batch_f32tol(c, (uint64_t)(uintptr_t)fd, batch, (uint64_t)(uintptr_t)rd, nullptr);
+    if (rc == YOLO2_SUCCESS) {
+        hipError_t e = hipMemcpy(region, rd, (size_t)batch * YOLO2_REGION_ELEMS * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(YOLO2_DMA_ERROR, "D2H of region tensor failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(fd);
+    (void)hipFree(rd);
+    return rc;
+}
+
+// Kernel the split-mode table runs for layer `layer_idx` (after the first yolo2_hip_run_batch_f32tol at this batch); "" if none.
+extern "C" const char *yolo2_hip_f32tol_layer_kernel(yolo2_hip_ctx *c, int layer_idx) { return c && c->tol ? yolo2_hip_fp16_layer_kernel(c->tol, layer_idx) : ""; }
+extern "C" int yolo2_hip_num_lanes_f32tol(yolo2_hip_ctx *c) { return c && c->tol && !c->tol->f16_lanes.empty() ? (int)c->tol->f16_lanes.size() : 1; }
 
 #ifdef Y2_STAMPS
 // diagnostic build only: the halo kernel's workgroup timeline of the launch selected by YOLO2_STAMP_LAYER

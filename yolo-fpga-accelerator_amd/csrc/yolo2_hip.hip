@@ -283,11 +283,14 @@ extern "C" void yolo2_hip_destroy(yolo2_hip_ctx *c)
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     for (yolo2_hip_ctx *l : c->f16_lanes) yolo2_hip_destroy(l);
     c->f16_lanes.clear();
+    if (c->tol) yolo2_hip_destroy(c->tol);
+    c->tol = nullptr;
     if (c->is_lane) {   // packed weights and biases belong to the parent
         c->wpk = nullptr;
         c->bias_pk = nullptr;
         c->wh = nullptr; c->biasf = nullptr; c->w0f = nullptr; c->wf32 = nullptr; c->bf32 = nullptr;
     }
+    if (c->borrows_f32) { c->w0f = nullptr; c->wf32 = nullptr; c->bf32 = nullptr; }   // the split-mode twin: its wh / biasf are its own
     y2_free_f16_activations(c);
     y2_free_f32_activations(c);
     if (c->wpkf) (void)hipFree(c->wpkf);
@@ -335,6 +338,7 @@ extern "C" int yolo2_hip_set_profiling(yolo2_hip_ctx *c, int enable)
     }
     c->prof = enable != 0;
     c->prof_runs = 0;  // (re)start the averaging window
+    if (c->tol) (void)yolo2_hip_set_profiling(c->tol, enable);                              // the split-mode twin follows its parent
     if (!c->f16_lanes.empty()) return yolo2_hip_set_profiling(c->f16_lanes[0], enable);   // fp16 lanes: lane 0 is reported
     return YOLO2_SUCCESS;
 }
@@ -343,6 +347,8 @@ extern "C" int yolo2_hip_layer_times_ms(yolo2_hip_ctx *c, float *ms32)
 {
     if (!c || !ms32) return fail(YOLO2_ERROR, "null argument");
     if (c->laned) return yolo2_hip_layer_times_ms(c->lanes[0], ms32);
+    if (c->prof_runs == 0 && !c->f16_lanes.empty() && c->f16_lanes[0]->prof_runs > 0) return yolo2_hip_layer_times_ms(c->f16_lanes[0], ms32);
+    if (c->prof_runs == 0 && c->tol) return yolo2_hip_layer_times_ms(c->tol, ms32);   // only the split-mode twin has run since profiling was switched on
     if (c->prof_runs == 0 && !c->f16_lanes.empty()) return yolo2_hip_layer_times_ms(c->f16_lanes[0], ms32);
     if (c->prof_runs == 0) return fail(YOLO2_ERROR, "no profiled run yet");
     const int n = (int)std::min<long>(c->prof_runs, yolo2_hip_ctx::kProfSlots);

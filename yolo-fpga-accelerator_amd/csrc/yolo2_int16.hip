@@ -1166,6 +1166,15 @@ extern "C" int yolo2_hip_plan_source(yolo2_hip_ctx *c)
     return c->plan_source;
 }
 
+// Bytes of the K-split kernel's triple scratch this context holds for its current batch (lane 0's with lanes; 0 = none):
+// exactly the largest splits x items x pixels x 24 among the accepted plans.
+extern "C" size_t yolo2_hip_ks_scratch_bytes(yolo2_hip_ctx *c)
+{
+    if (!c) return 0;
+    if (c->laned && !c->lanes.empty()) return c->lanes[0]->ks_trip_bytes;
+    return c->ks_trip_bytes;
+}
+
 extern "C" int yolo2_hip_layer_pool_fused(yolo2_hip_ctx *c, int layer_idx)
 {
     if (!c || layer_idx < 0 || layer_idx > 31 || !c->batch) return 0;

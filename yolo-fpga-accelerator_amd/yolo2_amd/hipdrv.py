@@ -44,7 +44,8 @@ EXPORTS = [
     "yolo2_hip_fp16_layer_kernel", "yolo2_hip_f16_store_check",
     "yolo2_hip_run_images_u8_dets", "yolo2_hip_multi_run_images_u8_dets", "yolo2_hip_set_fp16_lanes", "yolo2_hip_conv_plan_string", "yolo2_hip_plan_source",
     "yolo2_hip_set_option", "yolo2_hip_options_string", "yolo2_hip_set_plan_cache", "yolo2_hip_plan_cache_info", "yolo2_hip_plan_cache_check",
-    "yolo2_hip_i16_plan_check",
+    "yolo2_hip_i16_plan_check", "yolo2_hip_ks_scratch_bytes",
+    "yolo2_hip_run_batch_f32tol", "yolo2_hip_run_batch_f32tol_host", "yolo2_hip_f32tol_layer_kernel", "yolo2_hip_num_lanes_f32tol",
 ]
 
 
@@ -139,6 +140,13 @@ def lib():
     L.yolo2_hip_plan_cache_info.argtypes = [vp, C.POINTER(u64), pi32, pi32, pi32]
     L.yolo2_hip_plan_cache_check.argtypes = [C.c_char_p, u64, pi32]
     L.yolo2_hip_i16_plan_check.argtypes = [i32, i32, i32, C.c_size_t]
+    L.yolo2_hip_run_batch_f32tol.argtypes = [vp, u64, i32, u64, vp]
+    L.yolo2_hip_run_batch_f32tol_host.argtypes = [vp, vp, i32, vp]
+    L.yolo2_hip_f32tol_layer_kernel.argtypes = [vp, i32]
+    L.yolo2_hip_f32tol_layer_kernel.restype = C.c_char_p
+    L.yolo2_hip_num_lanes_f32tol.argtypes = [vp]
+    L.yolo2_hip_ks_scratch_bytes.argtypes = [vp]
+    L.yolo2_hip_ks_scratch_bytes.restype = C.c_size_t
     L.yolo2_hip_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.yolo2_hip_multi_destroy.argtypes = [vp]
     L.yolo2_hip_multi_num_devices.argtypes = [vp]
@@ -440,6 +448,24 @@ class Yolo2Hip:
         check(lib().yolo2_hip_layer_times_ms(self._h, ms.ctypes.data_as(C.c_void_p)), "yolo2_hip_layer_times_ms")
         return ms
 
+    # ---- split-fp16 ("fp32 fast"): fp32 accuracy on the matrix cores
+    def run_batch_f32tol_host(self, frames: np.ndarray) -> np.ndarray:
+        f = np.ascontiguousarray(frames, dtype=np.float32)
+        batch = f.shape[0]
+        region = np.empty((batch, 425, 13, 13), dtype=np.float32)
+        check(lib().yolo2_hip_run_batch_f32tol_host(self._h, f.ctypes.data_as(C.c_void_p), batch, region.ctypes.data_as(C.c_void_p)),
+              "yolo2_hip_run_batch_f32tol_host")
+        return region
+
+    def run_batch_f32tol_ptr(self, frames_ptr: int, batch: int, region_ptr: int, stream: int = 0):
+        check(lib().yolo2_hip_run_batch_f32tol(self._h, frames_ptr, batch, region_ptr, C.c_void_p(stream)), "yolo2_hip_run_batch_f32tol")
+
+    def f32tol_layer_kernel(self, layer_idx: int) -> str:
+        return lib().yolo2_hip_f32tol_layer_kernel(self._h, layer_idx).decode()
+
+    def num_lanes_f32tol(self) -> int:
+        return int(lib().yolo2_hip_num_lanes_f32tol(self._h))
+
     def set_fp16_lanes(self, lanes: int):
         check(lib().yolo2_hip_set_fp16_lanes(self._h, lanes), "yolo2_hip_set_fp16_lanes")
 
@@ -458,6 +484,9 @@ class Yolo2Hip:
         buf = C.create_string_buffer(1024)
         check(lib().yolo2_hip_options_string(self._h, buf, 1024), "yolo2_hip_options_string")
         return buf.value.decode()
+
+    def ks_scratch_bytes(self) -> int:
+        return int(lib().yolo2_hip_ks_scratch_bytes(self._h))
 
     def set_plan_cache(self, path):
         check(lib().yolo2_hip_set_plan_cache(self._h, None if path is None else str(path).encode()), "yolo2_hip_set_plan_cache")
