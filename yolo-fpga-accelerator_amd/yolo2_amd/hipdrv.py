@@ -134,19 +134,24 @@ def lib():
     L.yolo2_hip_postprocess_int16.argtypes = [vp, u64, i32, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
     L.yolo2_hip_postprocess_f32.argtypes = [vp, u64, i32, vp, vp, C.c_float, C.c_float, vp, i32, vp, vp, vp, vp, vp]
     L.yolo2_hip_shard_range.argtypes = [i32, i32, i32, pi32, pi32]
-    L.yolo2_hip_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
-    L.yolo2_hip_options_string.argtypes = [vp, C.c_char_p, i32]
-    L.yolo2_hip_set_plan_cache.argtypes = [vp, C.c_char_p]
-    L.yolo2_hip_plan_cache_info.argtypes = [vp, C.POINTER(u64), pi32, pi32, pi32]
-    L.yolo2_hip_plan_cache_check.argtypes = [C.c_char_p, u64, pi32]
-    L.yolo2_hip_i16_plan_check.argtypes = [i32, i32, i32, C.c_size_t]
-    L.yolo2_hip_run_batch_f32tol.argtypes = [vp, u64, i32, u64, vp]
-    L.yolo2_hip_run_batch_f32tol_host.argtypes = [vp, vp, i32, vp]
-    L.yolo2_hip_f32tol_layer_kernel.argtypes = [vp, i32]
-    L.yolo2_hip_f32tol_layer_kernel.restype = C.c_char_p
-    L.yolo2_hip_num_lanes_f32tol.argtypes = [vp]
-    L.yolo2_hip_ks_scratch_bytes.argtypes = [vp]
-    L.yolo2_hip_ks_scratch_bytes.restype = C.c_size_t
+    # (an older build loaded through YOLO2_HIP_LIB for an A/B run may lack the newer entries: their signatures are set when present)
+    def sig(name, argtypes, restype=None):
+        f = getattr(L, name, None)
+        if f is not None:
+            f.argtypes = argtypes
+            if restype is not None:
+                f.restype = restype
+    sig("yolo2_hip_set_option", [vp, C.c_char_p, C.c_char_p])
+    sig("yolo2_hip_options_string", [vp, C.c_char_p, i32])
+    sig("yolo2_hip_set_plan_cache", [vp, C.c_char_p])
+    sig("yolo2_hip_plan_cache_info", [vp, C.POINTER(u64), pi32, pi32, pi32])
+    sig("yolo2_hip_plan_cache_check", [C.c_char_p, u64, pi32])
+    sig("yolo2_hip_i16_plan_check", [i32, i32, i32, C.c_size_t])
+    sig("yolo2_hip_run_batch_f32tol", [vp, u64, i32, u64, vp])
+    sig("yolo2_hip_run_batch_f32tol_host", [vp, vp, i32, vp])
+    sig("yolo2_hip_f32tol_layer_kernel", [vp, i32], C.c_char_p)
+    sig("yolo2_hip_num_lanes_f32tol", [vp])
+    sig("yolo2_hip_ks_scratch_bytes", [vp], C.c_size_t)
     L.yolo2_hip_multi_create.argtypes = [vp, i32, C.POINTER(vp)]
     L.yolo2_hip_multi_destroy.argtypes = [vp]
     L.yolo2_hip_multi_num_devices.argtypes = [vp]
@@ -481,6 +486,8 @@ class Yolo2Hip:
         check(lib().yolo2_hip_set_option(self._h, name.encode(), None if value is None else str(value).encode()), f"yolo2_hip_set_option({name})")
 
     def options(self) -> str:
+        if not hasattr(lib(), "yolo2_hip_options_string"):
+            return "(library without option sets)"
         buf = C.create_string_buffer(1024)
         check(lib().yolo2_hip_options_string(self._h, buf, 1024), "yolo2_hip_options_string")
         return buf.value.decode()
