@@ -88,6 +88,9 @@ __device__ __forceinline__ int flat_of_fast(const ConvF16Args &a, int q)
     return b * a.PL + (y + 1) * a.Wp + x;
 }
 
+#ifndef Y2_C0_ABL
+#define Y2_C0_ABL 0         // diagnostic builds of k_conv0_pool_mfma: 1 = no global stores, 2 = cache-hot loads, 4 = no gathers / MFMAs / pooling
+#endif
 #ifndef Y2_ABL
 #define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile
 #endif
@@ -1702,19 +1705,27 @@ __global__ void k_maxpool2_f16(const _Float16 *__restrict__ in, _Float16 *__rest
     *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(y + 1) * oWp + x) * Cp + ck * 8) = o;
 }
 
-// Darknet legacy reorg (yolo2_model.cpp:112-129) into channels [0,256) of the 1280-channel concat items
+// Darknet legacy reorg (yolo2_model.cpp:112-129) into channels [0,256) of the 1280-channel concat items.  One thread per (frame,
+// output pixel, PAIR of output channels): consecutive lanes write consecutive 4-byte pieces of one item (coalesced), the two halves
+// are gathered from the 64-channel source items.  (Round 3's one-thread-per-element form in [channel][pixel] order wrote 2-byte
+// pieces 2560 bytes apart: 0.052 ms per 128 frames, as much as a 1x1 conv layer.)
 __global__ void k_reorg_f16(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int B, int iCp, int iWp, int iPL,
                             int oCp, int oWp, int oPL)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * 256 * 169) return;
-    const int b = t / (256 * 169), o = t - b * (256 * 169);
-    const int k = o / (26 * 416), rem = o - k * (26 * 416), j = rem / 26, i = rem - j * 26;
-    const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));
-    const int sc = sidx / 676, sr = sidx - sc * 676, sy = sr / 26, sx = sr - sy * 26;
-    const _Float16 v = in[((size_t)kLead + (size_t)b * iPL + (size_t)(sy + 1) * iWp + sx) * iCp + sc];
-    const int oc = o / 169, orr = o - oc * 169, oy = orr / 13, ox = orr - oy * 13;
-    out[((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * oCp + oc] = v;
+    if (t >= B * 169 * 128) return;
+    const int cp = t & 127, pix = (t >> 7) % 169, b = t / (169 * 128);
+    const int oy = pix / 13, ox = pix - oy * 13;
+    half2_t v;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int o = (2 * cp + e) * 169 + pix;        // the reference's flat output index [256][13][13]
+        const int k = o / (26 * 416), rem = o - k * (26 * 416), j = rem / 26, i = rem - j * 26;
+        const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));
+        const int sc = sidx / 676, sr = sidx - sc * 676, sy = sr / 26, sx = sr - sy * 26;
+        v[e] = in[((size_t)kLead + (size_t)b * iPL + (size_t)(sy + 1) * iWp + sx) * iCp + sc];
+    }
+    *reinterpret_cast<half2_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * oCp + 2 * cp) = v;
 }
 
 // weights_reorg (fp32 stream of one layer) -> wh[N_pad][KK][Cp] halves (zero padded).
@@ -1757,8 +1768,10 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
                                                           const float *__restrict__ bias0, _Float16 *__restrict__ out, int H,
                                                           int W, int oWp, int oPL, int n_tile_total)
 {
-    constexpr int TR = 16, TC = 32, PR = TR + 2, PC = TC + 2, PCS = 36;   // patch rows / cols / row stride (halves)
-    __shared__ _Float16 patch[3 * PR * PCS];
+    // Patch = rows ty0-1 .. ty0+16, image columns tx0-4 .. tx0+35 (the tile's 34 plus three on either side so that every piece is
+    // a 16-byte aligned float4 in the frame: tx0 is a multiple of 32): column tx0-1+p is stored at index p + PSH of its row.
+    constexpr int TR = 16, TC = 32, PR = TR + 2, PCS = 40, PSH = 3, PV = 10;   // patch rows / row stride (halves) / shift / float4 pieces per row
+    __shared__ __attribute__((aligned(16))) _Float16 patch[3 * PR * PCS];
     __shared__ __attribute__((aligned(16))) _Float16 otile[8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W / TC, tiles_y = H / TR;
@@ -1774,7 +1787,7 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             const int k = 16 * kk + 8 * h + j;
             bfrag[kk][j] = k < 27 ? (_Float16)w0[k * 32 + n] : (_Float16)0.f;
             const int c = k / 9, tap = k - c * 9;
-            aoff[kk][j] = k < 27 ? (c * PR + tap / 3) * PCS + tap % 3 : 0;
+            aoff[kk][j] = k < 27 ? (c * PR + tap / 3) * PCS + tap % 3 + PSH : PSH;
         }
     const float bv = bias0[n];
     // this lane's pixel inside an MFMA block: row r = 4*pc + 2*dy + dx
@@ -1783,25 +1796,31 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
     // The workgroup is PERSISTENT (round 3): it walks tiles blockIdx.x, + gridDim.x, ... and requests tile t + 1's patch
     // (registers) right after tile t's has been written to LDS, so the loads are in flight during tile t's gathers, MFMAs and
     // stores.  One tile per workgroup kept only a quarter of a workgroup's life's worth of bytes in flight: 2.2 TB/s.
-    constexpr int NEL = 3 * PR * PC, NIT = (NEL + 255) / 256;
-    // patch element i of this thread (the same for every tile): plane c, patch row py, patch column px
-    int pel_off[NIT], pel_pk[NIT];   // LDS offset; py | px << 8 | c << 16
+    // Staging (round 4): 3 x 18 rows x 10 aligned float4 pieces = 540 pieces per tile, up to three per thread, each converted and
+    // written to LDS as ONE 8-byte piece.  (Round 3 loaded the 1836 patch elements as 4-byte pieces that started 4 bytes before a
+    // 128-byte line and wrote them with 2-byte LDS stores; with every request aimed at one cache-hot patch - Y2_C0_ABL = 2 - the
+    // kernel took 0.160 instead of 0.237 ms per 128 frames: the loads, not the gathers, were what it waited for.)
+    constexpr int NPC = 3 * PR * PV, NIT = (NPC + 255) / 256;
+    int pel_off[NIT], pel_pk[NIT];   // LDS offset (halves) of the piece; py | j << 8 | c << 16
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int i = min(tid + it * 256, NEL - 1);
-        const int c = i / (PR * PC), r2 = i - c * (PR * PC), py = r2 / PC, px = r2 - py * PC;
-        pel_pk[it] = py | (px << 8) | (c << 16);
-        pel_off[it] = (c * PR + py) * PCS + px;
+        const int i = min(tid + it * 256, NPC - 1);
+        const int row = i / PV, j = i - row * PV, c = row / PR, py = row - c * PR;
+        pel_pk[it] = py | (j << 8) | (c << 16);
+        pel_off[it] = row * PCS + 4 * j;
     }
-    float pv[NIT];
-    auto request = [&](int tile) {   // rows ty0-1 .. ty0+16, cols tx0-1 .. tx0+32; clamped addresses, masked when written
+    float4 pv[NIT];
+    auto request = [&](int tile) {   // clamped addresses (always inside the plane), masked when written
+#if (Y2_C0_ABL & 2)
+        tile = (int)blockIdx.x;          // diagnostic: every request re-reads the workgroup's first (cache-hot) patch
+#endif
         const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
         const float *fb = frames + (size_t)b * 3 * H * W;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 + ((pel_pk[it] >> 8) & 255) - 1;
-            pv[it] = fb[((size_t)(pel_pk[it] >> 16) * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 1)];
+            const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 - 4 + 4 * ((pel_pk[it] >> 8) & 255);
+            pv[it] = *reinterpret_cast<const float4 *>(fb + ((size_t)(pel_pk[it] >> 16) * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 4));
         }
     };
     if ((int)blockIdx.x < n_tile_total) request((int)blockIdx.x);
@@ -1811,14 +1830,19 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
-            if (i < NEL) {
-                const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 + ((pel_pk[it] >> 8) & 255) - 1;
-                patch[pel_off[it]] = (sy >= 0 && sy < H && sx >= 0 && sx < W) ? (_Float16)pv[it] : (_Float16)0.f;
+            if (i < NPC) {
+                const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 - 4 + 4 * ((pel_pk[it] >> 8) & 255);
+                const bool rowok = sy >= 0 && sy < H, colok = sx >= 0 && sx < W;      // (a piece is wholly inside or wholly outside the image: W % 4 == 0)
+                typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+                half4_t hv = {(_Float16)pv[it].x, (_Float16)pv[it].y, (_Float16)pv[it].z, (_Float16)pv[it].w};
+                if (!(rowok && colok)) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                *reinterpret_cast<half4_t *>(&patch[pel_off[it]]) = hv;
             }
         }
         __syncthreads();   // the patch is complete; everybody has stored the previous tile's pooled rows
         if (tile + (int)gridDim.x < n_tile_total) request(tile + (int)gridDim.x);
 
+#if !(Y2_C0_ABL & 4)
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb) {
             const int prow = wave * 2 + (mb >> 1), chalf = mb & 1;            // pooled row 0..7, column half 0..1 of the tile
@@ -1841,17 +1865,26 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
                 otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
             }
         }
+#endif
         __syncthreads();   // the pooled tile is complete; nobody reads the patch any more
         // 128 pooled pixels x 4 chunks of 8 channels = 512 16-byte stores, two per thread
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int e = tid + it * 256, pp = e >> 2, ck = e & 3;
             const int oy = ty0 / 2 + (pp >> 4), ox = tx0 / 2 + (pp & 15);
+#if (Y2_C0_ABL & 1)
+            if (oy < 0)                  // diagnostic: no global stores
+#endif
             *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + ck * 8) =
                 *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
         }
     }
 }
+
+// (Round 4 also built a second form with the im2col expansion on the B side - an MFMA row = four adjacent conv pixels, K = (channel,
+//  patch row, 8-column window), so that a fragment is two ds_read_b64 instead of eight ds_read_u16, 20 MFMAs per block instead of 8:
+//  0.241 against 0.231 ms per 128 frames, i.e. NO gain - the kernel was waiting for its global loads, not for its gathers; removed.
+//  What paid was the staging above: 0.237 -> 0.189 ms.)
 
 // layer-0 weights for k_conv0_pool_f16: weights_reorg fp32 (C=3, N=32, 3x3) -> w0[k = c*9 + tap][n]
 __global__ void k_pack_w0_f32(const float *__restrict__ src, const float *__restrict__ bias_src, float *__restrict__ w0,

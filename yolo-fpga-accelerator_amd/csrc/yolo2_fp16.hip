@@ -28,7 +28,8 @@ struct F16Switches {
     bool ring_all = false, no_ring = false, no_c32 = false, m16 = false, w8 = false, no_wide = false;
     int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
     bool verbose = false;
-    bool no_fuse1x1 = false, no_rw = false, no_im2col0 = false;
+    int skip = 0;             // diagnostic: see Y2Options::f16_skip
+    bool no_fuse1x1 = false, no_rw = false;
     static F16Switches from_options(const Y2Options &o)   // the context's option set (y2_internal.hpp), latched at weight load
     {
         F16Switches s;
@@ -37,9 +38,10 @@ struct F16Switches {
         s.no_halo = o.f16_no_halo; s.no_persist = o.f16_no_persist; s.persist_all = o.f16_persist_all;
         s.ring_all = o.f16_ring_all; s.no_ring = o.f16_no_ring; s.no_c32 = o.f16_no_c32;
         s.m16 = o.f16_m16; s.w8 = o.f16_w8; s.no_wide = o.f16_no_wide;
-        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_im2col0 = o.f16_no_im2col0;
+        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw;
         s.stamp_layer = o.stamp_layer;
         s.verbose = o.verbose;
+        s.skip = o.f16_skip;
         return s;
     }
 };
@@ -524,7 +526,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             s.layer = i; s.B = B; s.kernel = "k_reorg_f16"; s.launch = L_reorg;
             s.in = gi.d; s.out = go.d; s.iCp = gi.Cp; s.iWp = gi.Wp; s.iPL = gi.PL; s.oCp = go.Cp; s.oWp = go.Wp; s.oPL = go.PL;
             if (split) { s.kernel = "k_reorg_split"; s.launch = L_reorg_split; s.iPS = part_stride(gi.C); s.oPS = part_stride(go.C); }
-            s.grid = dim3(blocks_for((long)B * 256 * 169, 256)); s.block = dim3(256);
+            s.grid = dim3(blocks_for((long)B * (split ? 256 : 128) * 169, 256)); s.block = dim3(256);   // (fp16: one thread per channel pair)
             P.steps.push_back(s);
             cur = &c->h_cat;
             break;
@@ -532,6 +534,21 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         default:
             break;  // route: concat by placement; region: the last conv already wrote the dense fp32 tensor
         }
+    }
+    if (sw.skip) {   // diagnostic only: drop launches from the table (wrong results), to price them inside the overlapped step
+        std::vector<F16Step> kept;
+        for (const F16Step &s : P.steps) {
+            const LayerDesc &l = kNet[s.layer];
+            bool drop = false;
+            if ((sw.skip & 1) && (s.layer == 5 || s.layer == 9)) drop = true;
+            if ((sw.skip & 2) && s.layer == 0) drop = true;
+            if ((sw.skip & 4) && (s.layer == 2 || s.layer == 4 || s.layer == 6)) drop = true;
+            if ((sw.skip & 8) && (l.type == L_MAX || l.type == L_REORG)) drop = true;
+            if ((sw.skip & 16) && l.type == L_CONV && l.size == 1 && s.layer != 5 && s.layer != 9) drop = true;
+            if ((sw.skip & 32) && l.type == L_CONV && l.size == 3 && l.w == 13) drop = true;
+            if (!drop) kept.push_back(s);
+        }
+        P.steps = kept;
     }
     P.batch = B;
     if (sw.verbose)   // (plan construction, not the launch path)

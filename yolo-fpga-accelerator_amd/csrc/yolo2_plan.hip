@@ -31,12 +31,12 @@ const FlagOpt kFlags[] = {
     {"f16_no_poolfuse", &Y2Options::f16_no_poolfuse}, {"f16_no_halo", &Y2Options::f16_no_halo}, {"f16_no_persist", &Y2Options::f16_no_persist},
     {"f16_persist_all", &Y2Options::f16_persist_all}, {"f16_ring_all", &Y2Options::f16_ring_all}, {"f16_no_ring", &Y2Options::f16_no_ring},
     {"f16_no_c32", &Y2Options::f16_no_c32}, {"f16_m16", &Y2Options::f16_m16}, {"f16_w8", &Y2Options::f16_w8}, {"f16_no_wide", &Y2Options::f16_no_wide},
-    {"f16_no_fuse1x1", &Y2Options::f16_no_fuse1x1}, {"f16_no_rw", &Y2Options::f16_no_rw}, {"f16_no_im2col0", &Y2Options::f16_no_im2col0},
+    {"f16_no_fuse1x1", &Y2Options::f16_no_fuse1x1}, {"f16_no_rw", &Y2Options::f16_no_rw},
 };
 const IntOpt kInts[] = {
     {"autotune", &Y2Options::autotune, -1, 1}, {"lanes", &Y2Options::lanes, 0, 8}, {"lane_priority", &Y2Options::lane_priority, 0, 1},
     {"splitk", &Y2Options::splitk, -1, 1}, {"poolfuse", &Y2Options::poolfuse, -1, 1}, {"f16_lanes", &Y2Options::f16_lanes, 1, 8},
-    {"stamp_layer", &Y2Options::stamp_layer, -1, 31}, {"force_path", &Y2Options::force_path, -1, 4}, {"force_p", &Y2Options::force_p, 0, 8},
+    {"stamp_layer", &Y2Options::stamp_layer, -1, 31}, {"f16_skip", &Y2Options::f16_skip, 0, 63}, {"force_path", &Y2Options::force_path, -1, 4}, {"force_p", &Y2Options::force_p, 0, 8},
     {"force_ks", &Y2Options::force_ks, 0, 16}, {"f32_p", &Y2Options::f32_p, 0, 4},
 };
 const StrOpt kStrs[] = {
