@@ -607,13 +607,14 @@ def test_fp16_mfma_path_vs_fp32_reference():
     # the launch table (built once per batch; the YOLO2_F16_* switches are latched when the weights are loaded)
     kern = ctx.fp16_layer_kernels()
     assert kern[0] == "k_conv0_pool_mfma" and kern[2] == "k_conv_f16_c32_pool" and kern[30].startswith("k_gemm1_f16_p")
-    assert kern[4].startswith("k_conv_f16_halo_p") and kern[22].startswith("k_conv_f16_halo<256")
+    assert kern[4] == "k_conv_f16_rw<+1x1>" and 5 not in kern and kern[6] == "k_conv_f16_rw<pool>" and kern[22].startswith("k_conv_f16_halo<256")
     assert 1 not in kern and 3 not in kern, "pools fused into the convs before them must have no launch of their own"
     ctx.close()
 
 
 @pytest.mark.parametrize("env", ["YOLO2_F16_NO_HALO", "YOLO2_F16_NO_WIDE", "YOLO2_F16_NO_MFMA0", "YOLO2_F16_NO_GLDS", "YOLO2_F16_NO_POOLFUSE", "YOLO2_F16_W8",
-                                 "YOLO2_F16_NO_PERSIST", "YOLO2_F16_PERSIST_ALL", "YOLO2_F16_M16", "YOLO2_F16_RING_ALL", "YOLO2_F16_NO_RING", "YOLO2_F16_NO_C32"])
+                                 "YOLO2_F16_NO_PERSIST", "YOLO2_F16_PERSIST_ALL", "YOLO2_F16_M16", "YOLO2_F16_RING_ALL", "YOLO2_F16_NO_RING", "YOLO2_F16_NO_C32",
+                                 "YOLO2_F16_NO_RW", "YOLO2_F16_NO_FUSE1X1"])
 def test_fp16_kernel_variants_agree(env, monkeypatch):
     """Every fp16 conv kernel family against the fp32 oracle on a ragged batch (5 frames: partial
     256-pixel tiles on every layer), and against the default selection: the halo-tile kernel vs the

@@ -1185,6 +1185,298 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__r
 }
 
 
+// ---- register-resident weights: the 64 -> 128 channel 3x3 layers at 104 x 104 (layers 4 and 6) ---------------------------------
+// These two layers (K = 576, N = 128) ran at 0.69-0.78 PF against 1.0 for the 26 x 26 layers: with only 128 output channels a
+// tap-step of the halo kernels is 1024 MFMA cycles per SIMD between two barriers (half of the 256-channel tiles'), and the weight
+// tile - 147 KB per 256 pixels, re-staged for every pixel tile - is 70 % of what the LDS-DMA moves.  Here NOTHING is staged per tap:
+//   * a workgroup is four wavefronts, one per SIMD; wavefront w owns output channels 32 w .. 32 w + 31 and keeps ITS slice of the
+//     weights - all nine taps x 64 input channels = 36 fragments of v_mfma_f32_16x16x32_f16 - in 144 registers for the whole kernel;
+//   * a tile is TWO IMAGE ROWS (2 x 104 = 208 pixels = 13 blocks of 16 MFMA rows), staged once with its halo rows (dense in pixel
+//     index, XOR swizzle and zero-row masking as in k_conv_f16_halo) into one of two LDS buffers by LDS-DMA while the previous tile
+//     is multiplied: ONE barrier per tile, 468 MFMAs per wavefront between barriers;
+//   * MFMA rows are ordered m = 4 w + 2 dy + dx over 2x2 pool windows w (a block = 4 windows), so that
+//       MODE 1 (layer 6, whose only consumer is the pool): D rows = pixels, the four members of a window are the four registers of
+//              one lane - in-lane max, bias + leaky (monotonic), the pooled row leaves through a small LDS tile in 16-byte stores;
+//       MODE 0 (plain store) / MODE 2: operands swapped (D rows = channels): a lane holds 4 consecutive channels of a pixel;
+//       MODE 2 (layer 4 + layer 5): the 128-channel result of the 3x3 is consumed ONLY by the 1x1 after it (128 -> 64), so it is
+//              never written to memory: leaky'd fp16 [208 pixels][128 channels] into the LDS buffer the tile was read from, then
+//              52 more MFMAs per wavefront (its 16 of the 64 output channels, weights again in registers) and 8-byte stores of layer
+//              5's tensor.  Same bits as the two-kernel route's fp16 intermediate.
+// K order tap-major like k_conv_f16; operands fp16, accumulate fp32.  wh: [N][9][64] halves; wh2 (MODE 2): [64][1][128].
+// LDS slot swizzle of k_conv_f16_rw's input tile.  A v_mfma_f32_16x16x32_f16 fragment read puts lanes of TWO k-groups (kq, kq + 1:
+// slots s and s ^ 1) into one 16-lane ds_read_b128 group, on the rows {+0,1,104,105,6,7,110,111} and {+2,3,106,107,4,5,108,109} of
+// the window ordering; the halo kernels' key (row >> 1) & 7 makes those two sets meet on the same bank slots for every second tile
+// base (2-way conflicts: the reads of a tile then take as long as its MFMAs).  This key only moves slot bits 1-2 - the k-group parity
+// keeps the two sets apart - and is conflict-free for every base row, both channel halves and both lane-group shapes (brute-forced).
+#ifndef Y2_RW_ABL
+#define Y2_RW_ABL 0         // diagnostic builds of k_conv_f16_rw: 2 = no fragment reads, 4 = no epilogue, 8 = no input staging
+#endif
+// LDS slot swizzle of the input tile (the halo kernels' key).  (A key that only moves slot bits 1-2 - conflict-free by brute force for
+// the 16x16x32 fragment reads, where lanes of two k-groups share a ds_read_b128 lane group - measured 3 % SLOWER in the same box: the
+// reads are not what this kernel waits for.)
+__device__ __forceinline__ int rw_swz(int row) { return (row >> 1) & 7; }
+
+template <int NBLK, int MODE>
+__global__ __launch_bounds__(256) void k_conv_f16_rw(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh, const float *__restrict__ bias,
+                                                      _Float16 *__restrict__ out, const _Float16 *__restrict__ wh2, const float *__restrict__ bias2,
+                                                      const ConvF16Args a, const int lt_rows, const int n_tile_total)
+{
+    constexpr int ROWH = 64, BM = NBLK * 16, PD = 6;           // halves per LDS row; pixels per tile; A fragments in flight
+    constexpr int kCtP = 136, kTP = 136;                       // halves per row of the pooled tile / of the intermediate tile (MODE 2)
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    _Float16 *As = smem_h;                                     // [2][lt_rows][64]
+    _Float16 *Zs = smem_h + (size_t)2 * lt_rows * ROWH;        // [NBLK * 8][64] zeros: what a lane whose tap leaves the image reads (block k at + 8 k rows)
+    _Float16 *Cts = Zs + (size_t)NBLK * 8 * ROWH;              // MODE 1: [2][BM / 4][kCtP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HH = a.H >> 1;                                   // row pairs per image
+    // this workgroup's tiles (XCD-aware: XCD k owns a contiguous range, neighbouring row pairs share halo rows in its L2)
+    const int xcd = (int)blockIdx.x & 7, S = (int)gridDim.x >> 3;
+    const int t_first = (int)((long)n_tile_total * xcd / 8) + ((int)blockIdx.x >> 3);
+    const int t_end = (int)((long)n_tile_total * (xcd + 1) / 8);
+    const int my_n = t_first < t_end ? (t_end - t_first + S - 1) / S : 0;
+    if (my_n == 0) return;
+
+    for (int i = tid; i < NBLK * 8 * 8; i += 256) *reinterpret_cast<int4 *>(Zs + (size_t)i * 8) = make_int4(0, 0, 0, 0);
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const int n_stage = (2 * a.W + 2 * (a.W + 1) + 7) / 8;     // 8-row groups that hold real pixels
+    auto fill_a = [&](int ti) {                 // the halo tile of this workgroup's ti-th tile -> buffer ti & 1
+        const int t = t_first + ti * S, b = t / HH, y0 = 2 * (t - b * HH);
+        const int d0 = (b * a.H + y0) * a.W - a.W - 1;
+        const char *abase = reinterpret_cast<const char *>(act);
+        int lr = lrow, ls = lslot;
+        asm volatile("" : "+v"(lr), "+v"(ls));
+        for (int g = wave; g < n_stage; g += 4) {
+            const int row = g * 8 + lr;
+            const int d = min(max(d0 + row, 0), a.npix - 1);     // rows outside the tensor are only ever read masked
+            const unsigned src = ((unsigned)(kLead + flat_of_fast(a, d)) * 64u + (unsigned)((ls ^ rw_swz(row)) * 8)) * 2u;
+            lds_dma16(abase, src, As + ((size_t)(ti & 1) * lt_rows + g * 8) * ROWH);
+        }
+    };
+
+    // ---- resident weights: lane (i = lane & 15, kq = lane >> 4) holds k = 8 kq .. 8 kq + 7 of row / column i of every fragment
+    const int mi = lane & 15, kq = lane >> 4;
+    half8_t bfr[18][2];
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            bfr[s][cb] = *reinterpret_cast<const half8_t *>(wh + ((size_t)(32 * wave + 16 * cb + mi) * 9 + (s >> 1)) * 64 + 32 * (s & 1) + 8 * kq);
+    half8_t b2fr[MODE == 2 ? 4 : 1];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) b2fr[s2] = *reinterpret_cast<const half8_t *>(wh2 + (size_t)(16 * wave + mi) * 128 + 32 * s2 + 8 * kq);
+    }
+    // this lane's pixel inside a block: MFMA row / column mi = 4 (window in block) + 2 dy + dx
+    const int dy = (mi >> 1) & 1, dx = mi & 1, pwl = mi >> 2;
+    const int lo0 = (a.W + 1) + dy * a.W + 2 * pwl + dx;      // LDS row of the centre tap, block 0 (block k: + 8 k)
+
+    __syncthreads();                             // zero rows written
+    fill_a(0);
+
+    auto store_pooled_tile = [&](int ti) {       // MODE 1: the pooled row of tile ti from its LDS tile, 16 bytes per piece
+        const int t = t_first + ti * S, b = t / HH, oy = t - b * HH;
+        const _Float16 *Ct = Cts + (size_t)(ti & 1) * (BM / 4) * kCtP;
+#pragma unroll
+        for (int it = 0; it < (BM / 4 * 16 + 255) / 256; ++it) {
+            const int piece = tid + it * 256, px = piece >> 4, ck = piece & 15;
+            if (piece < BM / 4 * 16 && ck * 8 < a.n_store)
+                *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp + px) * a.Cp_out + a.out_ch_off + ck * 8) =
+                    *reinterpret_cast<const half8_t *>(Ct + (size_t)px * kCtP + ck * 8);
+        }
+    };
+
+    for (int ti = 0; ti < my_n; ++ti) {
+        const int t = t_first + ti * S, b = t / HH, y0 = 2 * (t - b * HH);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // tile ti is staged; everybody is done with buffer (ti + 1) & 1 and, MODE 1, has written Ct(ti - 1)
+        if constexpr (MODE == 1) { if (ti > 0) store_pooled_tile(ti - 1); }
+#if !(Y2_RW_ABL & 8)
+        if (ti + 1 < my_n) fill_a(ti + 1);
+#endif
+        const _Float16 *At = As + (size_t)(ti & 1) * lt_rows * ROWH;
+
+        acc_t acc[NBLK][2];
+#pragma unroll
+        for (int k = 0; k < NBLK; ++k)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) acc[k][cb] = acc_t{0.f, 0.f, 0.f, 0.f};
+
+        // A fragment `idx` = (tap, block, channel half): issued PD fragments ahead of the MFMAs that consume it
+        constexpr int NF = 9 * NBLK * 2;
+        const bool top = y0 == 0 && dy == 0, bot = y0 == a.H - 2 && dy == 1;
+        // LDS address of A fragment (tap, block, channel half).  Per tap a lane needs TWO registers: its row for block 0 is
+        // r0 = lo0 + tap offset, block k is 8 k rows (1024 bytes: the instruction's immediate offset) further, and the swizzle key
+        // ((row >> 1) & 7) of row r0 + 8 k is key(r0) ^ 4 (k & 1) - flipping slot bit 2, which is the same as taking the OTHER channel
+        // half's slot: E[h] = address of half h in block 0; block k, half h reads E[h ^ (k & 1)] + 1024 k.  A lane whose tap leaves
+        // the image (top / bottom image row: every block; left / right image column: block 0 / NBLK - 1 only) reads the zero region.
+        const unsigned at_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)At;
+        const unsigned z_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)Zs;
+        auto tap_base = [&](int tap, int h) -> unsigned {
+            const int ty = tap / 3, tx = tap - ty * 3;
+            const int r0 = lo0 + (ty - 1) * a.W + (tx - 1);
+            const unsigned e = at_lds + (unsigned)(r0 * (ROWH * 2) + (((4 * h + kq) ^ rw_swz(r0)) * 16));
+            return ((top && ty == 0) || (bot && ty == 2)) ? z_lds : e;
+        };
+        auto frag_base = [&](int idx) -> unsigned {
+            const int tap = idx / (NBLK * 2), rem = idx - tap * (NBLK * 2), blk = rem >> 1, hf = rem & 1, tx = tap % 3;
+            unsigned e = tap_base(tap, hf ^ (blk & 1));
+            if (blk == 0 && tx == 0) e = (pwl == 0 && dx == 0) ? z_lds : e;
+            if (blk == NBLK - 1 && tx == 2) e = (pwl == 3 && dx == 1) ? z_lds : e;
+            return e;
+        };
+        // Fragments travel in GROUPS of PD = 6 (three blocks x two channel halves) through two register sets: group g + 1 is read from
+        // LDS during the FIRST half of group g's MFMAs, so that its youngest read is >= 8 MFMAs (128 cycles) old when group g + 1
+        // starts.  The reads and their wait are INLINE ASM: with compiler-issued ds_read_b128 hipcc waited lgkmcnt(0) at a group's
+        // first use ALSO for the reads it had just issued for the next group (seen in the ISA: one full drain per two groups), and
+        // with ONE wavefront per SIMD nothing covers that latency.  After the wait a sched_barrier keeps every MFMA behind it
+        // (cdna_hip_programming.md 5.4 rule 18); inside a group the compiler is free to interleave address arithmetic, reads and MFMAs.
+        static_assert(NF % PD == 0 && PD == 6, "fragment groups");
+        half8_t fr[2][PD];
+#if (Y2_RW_ABL & 2)
+        auto issue1 = [&](int g, int i) { asm volatile("v_mov_b32 %0, %1" : "=v"(fr[g & 1][i][0]) : "v"(frag_base(g * PD + i)) : "memory"); };   // diagnostic: no LDS read
+#else
+        auto issue1 = [&](int g, int i) {
+            const int idx = g * PD + i, blk = (idx % (NBLK * 2)) >> 1;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[g & 1][i]) : "v"(frag_base(idx)), "i"(blk * 1024) : "memory");
+        };
+#endif
+#pragma unroll
+        for (int i = 0; i < PD; ++i) issue1(0, i);
+#pragma clang loop unroll(full)
+        for (int g = 0; g < NF / PD; ++g) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // group g's fragments (issued during group g - 1) have landed
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < PD; ++k) {
+                if (g + 1 < NF / PD && k < PD / 2) { issue1(g + 1, 2 * k); issue1(g + 1, 2 * k + 1); }
+                const int i = (k % 3) * 2 + k / 3;                     // blocks first, channel halves second: six MFMAs between two on one accumulator
+                const int idx = g * PD + i, tap = idx / (NBLK * 2), rem = idx - tap * (NBLK * 2), blk = rem >> 1, s = 2 * tap + (rem & 1);
+                const half8_t af = fr[g & 1][i];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    if constexpr (MODE == 1) acc[blk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bfr[s][cb], acc[blk][cb], 0, 0, 0);
+                    else acc[blk][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][cb], af, acc[blk][cb], 0, 0, 0);
+                }
+                if (k < PD / 2) __builtin_amdgcn_sched_barrier(0);     // (left alone, hipcc sinks the next group's reads to the end of this group)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+#if (Y2_RW_ABL & 4)
+        {   // diagnostic: no epilogue - one value per lane keeps the accumulators alive
+            float keep = 0.f;
+#pragma unroll
+            for (int k = 0; k < NBLK; ++k) keep += acc[k][0][0] + acc[k][1][3];
+            if (keep == 123.456f) out[tid] = (_Float16)keep;
+            continue;
+        }
+#endif
+        if constexpr (MODE == 1) {
+            // D row = 4 kq + r = window kq of the block, member r: the pool is a max over the four registers
+            _Float16 *Ct = Cts + (size_t)(ti & 1) * (BM / 4) * kCtP;
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int ch = 32 * wave + 16 * cb + mi;
+                const float bv = bias[ch];
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) {
+                    float v = fmaxf(fmaxf(acc[k][cb][0], acc[k][cb][1]), fmaxf(acc[k][cb][2], acc[k][cb][3])) + bv;
+                    if (a.leaky) v = fmaxf(v, v * 0.1f);
+                    Ct[(size_t)(4 * k + kq) * kCtP + ch] = (_Float16)v;
+                }
+            }
+        } else {
+            // D row = channel 4 kq + r of the 16-channel block, column = pixel mi of the block: 4 consecutive channels per lane
+            const int x0 = 2 * pwl + dx, y = y0 + dy;
+            if constexpr (MODE == 0) {
+                _Float16 *orow = out + ((size_t)kLead + (size_t)b * a.PL + (size_t)(y + 1) * a.Wp + x0) * a.Cp_out + a.out_ch_off;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int c0 = 32 * wave + 16 * cb + 4 * kq;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + c0);
+#pragma unroll
+                    for (int k = 0; k < NBLK; ++k) {
+                        float v0 = acc[k][cb][0] + bv.x, v1 = acc[k][cb][1] + bv.y, v2 = acc[k][cb][2] + bv.z, v3 = acc[k][cb][3] + bv.w;
+                        if (a.leaky) { v0 = fmaxf(v0, v0 * 0.1f); v1 = fmaxf(v1, v1 * 0.1f); v2 = fmaxf(v2, v2 * 0.1f); v3 = fmaxf(v3, v3 * 0.1f); }   // == (v < 0 ? 0.1 v : v), one instruction less
+                        const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                        if (c0 < a.n_store)
+                            *reinterpret_cast<uint2 *>(orow + (size_t)(8 * k) * a.Cp_out + c0) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                    }
+                }
+            } else {
+                // MODE 2: the 3x3's leaky'd fp16 result goes into the LDS buffer this tile was read from ([BM][kTP] halves, row = 16 block + mi)
+                __syncthreads();                 // every wavefront has finished reading the input tile
+                _Float16 *T = As + (size_t)(ti & 1) * lt_rows * ROWH;
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int c0 = 32 * wave + 16 * cb + 4 * kq;
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias + c0);
+#pragma unroll
+                    for (int k = 0; k < NBLK; ++k) {
+                        float v0 = acc[k][cb][0] + bv.x, v1 = acc[k][cb][1] + bv.y, v2 = acc[k][cb][2] + bv.z, v3 = acc[k][cb][3] + bv.w;
+                        if (a.leaky) { v0 = fmaxf(v0, v0 * 0.1f); v1 = fmaxf(v1, v1 * 0.1f); v2 = fmaxf(v2, v2 * 0.1f); v3 = fmaxf(v3, v3 * 0.1f); }   // == (v < 0 ? 0.1 v : v), one instruction less
+                        const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                        *reinterpret_cast<uint2 *>(T + (size_t)(16 * k + mi) * kTP + c0) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                    }
+                }
+                __syncthreads();
+                // the 1x1: out2[pixel][16 wave + 4 kq + r] = sum over 128 channels; operands swapped again (D rows = output channels)
+                acc_t acc2[NBLK];
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) acc2[k] = acc_t{0.f, 0.f, 0.f, 0.f};
+                // 4 k-slices x NBLK blocks = 52 fragments of the intermediate tile, in groups of 4 through two register sets, read by
+                // inline asm like the input tile's (compiler-issued reads wait lgkmcnt(0) each: ~100 cycles x 52 with one wavefront per SIMD)
+                {
+                    constexpr int PD2 = 4, NF2 = 4 * NBLK;
+                    static_assert(NF2 % PD2 == 0, "groups");
+                    const unsigned t_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)T + (unsigned)(mi * (kTP * 2) + 16 * kq);
+                    half8_t tf[2][PD2];
+                    auto issue2 = [&](int g, int i) {
+                        const int idx = g * PD2 + i, s2 = idx / NBLK, k = idx - s2 * NBLK;
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tf[g & 1][i]) : "v"(t_lds), "i"(16 * k * (kTP * 2) + 64 * s2) : "memory");
+                    };
+#pragma unroll
+                    for (int i = 0; i < PD2; ++i) issue2(0, i);
+#pragma clang loop unroll(full)
+                    for (int g = 0; g < NF2 / PD2; ++g) {
+                        if (g + 1 < NF2 / PD2) {
+#pragma unroll
+                            for (int i = 0; i < PD2; ++i) issue2(g + 1, i);
+                            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(PD2) : "memory");
+                        } else
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < PD2; ++i) {
+                            const int idx = g * PD2 + i, s2 = idx / NBLK, k = idx - s2 * NBLK;
+                            acc2[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2fr[s2], tf[g & 1][i], acc2[k], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                _Float16 *orow = out + ((size_t)kLead + (size_t)b * a.PL + (size_t)(y + 1) * a.Wp + x0) * a.Cp_out + a.out_ch_off;
+                const int c0 = 16 * wave + 4 * kq;
+                const float4 bv = *reinterpret_cast<const float4 *>(bias2 + c0);
+#pragma unroll
+                for (int k = 0; k < NBLK; ++k) {
+                    float v0 = acc2[k][0] + bv.x, v1 = acc2[k][1] + bv.y, v2 = acc2[k][2] + bv.z, v3 = acc2[k][3] + bv.w;
+                    if (a.leaky) { v0 = fmaxf(v0, v0 * 0.1f); v1 = fmaxf(v1, v1 * 0.1f); v2 = fmaxf(v2, v2 * 0.1f); v3 = fmaxf(v3, v3 * 0.1f); }   // == (v < 0 ? 0.1 v : v), one instruction less
+                    const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                    if (c0 < a.n_store)
+                        *reinterpret_cast<uint2 *>(orow + (size_t)(8 * k) * a.Cp_out + c0) = make_uint2(__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23));
+                }
+                // (the next iteration's barrier orders these reads of T before fill_a(ti + 2) overwrites the buffer)
+            }
+        }
+    }
+    if constexpr (MODE == 1) {
+        __syncthreads();
+        store_pooled_tile(my_n - 1);
+    }
+}
+
 // ---- 1x1 layers: persistent workgroups over a ring of staged K-steps --------------------------
 // A 1x1 layer is a plain GEMM [pixels x Cin] x [Cin x Cout] with 2 (layer 5) to 16 (layers 19/21/30) K-steps of 64
 // channels per tile: in the one-tile-per-workgroup kernels above its time is the per-tile set-up, the prologue fill

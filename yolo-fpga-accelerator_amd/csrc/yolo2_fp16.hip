@@ -66,8 +66,8 @@ struct F16Step {
     dim3 grid, block;
     unsigned lds = 0;
     int lt_rows = 0, T = 0;      // extra kernel arguments (halo tile rows, persistent kernels' tile count)
-    const _Float16 *in = nullptr, *w = nullptr;
-    const float *bias = nullptr, *w0 = nullptr;
+    const _Float16 *in = nullptr, *w = nullptr, *w2 = nullptr;     // w2 / bias2: the 1x1 layer fused behind a 3x3 (k_conv_f16_rw MODE 2)
+    const float *bias = nullptr, *w0 = nullptr, *bias2 = nullptr;
     _Float16 *out = nullptr;
     int B = 0;
     // pool / reorg steps: source and destination geometry (iPS / oPS: part strides of split items)
@@ -233,6 +233,9 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
@@ -304,6 +307,8 @@ template <int BN, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo_p, hipLaun
                                                                                             s.bias, s.out, s.a, s.lt_rows, s.T))
 template <int BN, int NB, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS, SP>), s.grid, s.block, s.lds, st, s.in,
                                                                                                   s.w, s.bias, s.out, s.a, s.lt_rows))
+template <int MODE> Y2_LAUNCHER(L_rw, hipLaunchKernelGGL((k_conv_f16_rw<13, MODE>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.w2, s.bias2, s.a,
+                                                       s.lt_rows, s.T))
 Y2_LAUNCHER(L_maxpool_split, hipLaunchKernelGGL(k_maxpool2_split, s.grid, s.block, 0, st, s.in, s.out, s.oPS, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
 Y2_LAUNCHER(L_reorg_split, hipLaunchKernelGGL(k_reorg_split, s.grid, s.block, 0, st, s.in, s.out, s.B, s.iPS, s.iCp, s.iWp, s.iPL, s.oPS, s.oCp, s.oWp, s.oPL))
 Y2_LAUNCHER(L_maxpool, hipLaunchKernelGGL(k_maxpool2_f16, s.grid, s.block, 0, st, s.in, s.out, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
@@ -347,12 +352,17 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         if (g.B != B || g.H != 208 || g.W != 208 || g.Cp != (split ? 128 : 32)) return fail(YOLO2_ERROR, "fp16 plan: layer-1 tensor has the wrong geometry");
         P.steps.push_back(s);
     }
-    int ord = 1, skip_pool = -1;
+    int ord = 1, skip_pool = -1, fused_conv = -1;
     const HT *cur = &c->h_out[1];
     for (int i = 2; i < 32; ++i) {
         const LayerDesc &l = kNet[i];
         switch (l.type) {
         case L_CONV: {
+            if (i == fused_conv) {   // this 1x1 layer ran inside the launch of the 3x3 before it (k_conv_f16_rw MODE 2): its tensor exists already
+                ord++;
+                cur = &c->h_out[i];
+                break;
+            }
             const HT *tin = i == 26 ? &c->h_out[16] : (i == 29 ? &c->h_cat : cur);
             const HT &tout = c->h_out[i];
             F16Step s;
@@ -399,6 +409,42 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             const bool in32 = ((size_t)kLead + (size_t)B * a.PL) * a.Cp_in * 2 < (1ull << 32);   // 32-bit byte offsets into the input
             int rc = YOLO2_SUCCESS;
             bool done = false;
+            // The 64 -> 128 channel 3x3 layers at 104 x 104 (4 and 6): weights resident in registers, two image rows per tile, one barrier
+            // per tile (k_conv_f16_rw).  Layer 6 fuses its pool (MODE 1); layer 4 fuses the 1x1 layer 5, its only consumer (MODE 2:
+            // the 128-channel tensor between them is never written); MODE 0 stores the plain tensor.
+            if (!done && !split && !sw.no_rw && l.size == 3 && a.Cp_in == 64 && l.n == 128 && l.w == 8 * 13 && (l.h & 1) == 0 && in32 && !sw.no_glds) {
+                const bool pool_here = kNet[i + 1].type == L_MAX && !sw.no_poolfuse;
+                const LayerDesc &nx = kNet[i + 1];
+                const bool fuse1 = !pool_here && !sw.no_fuse1x1 && nx.type == L_CONV && nx.size == 1 && nx.c == 128 && nx.n == 64 && nx.leaky == l.leaky &&
+                                   nx.h == l.h && nx.w == l.w && i + 1 != 16 && i + 1 != 24;   // (and nothing but layer i + 1 reads layer i: true for every conv of this network except 16)
+                s.T = B * (l.h / 2);
+                const int rounds = (s.T + 255) / 256;
+                s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8)))); s.block = dim3(256);
+                const int n_stage = (2 * l.w + 2 * (l.w + 1) + 7) / 8;
+                if (pool_here) {
+                    const HT &tp = c->h_out[i + 1];
+                    a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
+                    a.Cp_out = tp.Cp;
+                    s.out = tp.d; dst = &tp; skip_pool = i + 1;
+                    s.lt_rows = n_stage * 8;
+                    s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024 + 2 * (26 * 16 / 4 / 2) * 136 * 2);   // two input tiles + zero region + two pooled tiles
+                    s.kernel = "k_conv_f16_rw<pool>"; s.launch = L_rw<1>; s.store = FS_POOL_ONLY;
+                } else if (fuse1) {
+                    const HT &t2 = c->h_out[i + 1];
+                    a.Cp_out = t2.Cp; a.N = nx.n; a.n_store = round_up(nx.n, 32); a.out_ch_off = 0;
+                    s.out = t2.d; dst = &t2; fused_conv = i + 1;
+                    s.w2 = (const _Float16 *)(c->wh + c->wh_off[ord]);          // (ord was advanced above: the NEXT conv's weights)
+                    s.bias2 = (const float *)(c->biasf + c->biasf_off[ord]);
+                    s.lt_rows = std::max(n_stage, ((13 * 16 * 136 * 2 + 127) / 128 + 7) / 8) * 8;   // the 208 x 136-half intermediate tile must fit an input buffer
+                    s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024);
+                    s.kernel = "k_conv_f16_rw<+1x1>"; s.launch = L_rw<2>; s.store = FS_FULL;
+                } else {
+                    s.lt_rows = n_stage * 8;
+                    s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024);
+                    s.kernel = "k_conv_f16_rw"; s.launch = L_rw<0>; s.store = FS_FULL;
+                }
+                done = true;
+            }
             // 1x1 layers: persistent workgroups over a ring of staged K-steps (k_gemm1_f16_p)
             if (split && !bk64) return fail(YOLO2_ERROR, "fp16 plan (split): layer %d has %d-channel items, not a multiple of the 64-channel K-step", i, a.Cp_in);
             if (!done && l.size == 1 && bk64 && (i == 30 || (sw.ring_all && !split)) && in32 && !sw.no_ring) {
