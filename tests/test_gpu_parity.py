@@ -608,6 +608,7 @@ def test_fp16_mfma_path_vs_fp32_reference():
     kern = ctx.fp16_layer_kernels()
     assert kern[0] == "k_conv0_pool_mfma" and kern[2] == "k_conv_f16_c32_pool" and kern[30].startswith("k_gemm1_f16_p")
     assert kern[4] == "k_conv_f16_rw<+1x1>" and 5 not in kern and kern[6] == "k_conv_f16_rw<pool>" and kern[22].startswith("k_conv_f16_halo<256")
+    assert kern[8] == "k_conv_f16_halo<256,2,16>+1x1" and 9 not in kern, "layer 9 (1x1) runs inside layer 8's launch"
     assert 1 not in kern and 3 not in kern, "pools fused into the convs before them must have no launch of their own"
     ctx.close()
 

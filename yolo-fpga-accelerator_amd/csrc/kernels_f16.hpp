@@ -629,11 +629,18 @@ __global__ __launch_bounds__(256) void k_conv_f16_glds(const _Float16 *__restric
 // straddled an image-row end its rows skipped one and 39 % of the LDS cycles were bank conflicts.)
 // A dense tile has no zeros for out-of-image taps, so a lane whose tap leaves the image reads a
 // dedicated all-zero row instead (one v_cndmask on the address; identical addresses broadcast).
-template <int BN, int NB, int NW = 8, int TS = 32, bool SPLIT = false>
+// FUSE1 (BN = 256, 16 wavefronts, 32x32 MFMAs; layer 8 + layer 9): the tile holds ALL output channels of the 3x3 and its only consumer
+// is the 1x1 after it (256 -> 128): the leaky'd fp16 tile the epilogue lays out in LDS as [pixel][channel] is exactly the 1x1's
+// A operand, so the 1x1 runs on it right there - 32 more MFMAs per wavefront (64 pixels x 32 of the 128 output channels; its weight
+// fragments straight from L2 into registers) - and only the 1x1's tensor is stored (wh2: [128][1][256] halves; a.Cp_out / a.n_store
+// describe THAT tensor).  The 256-channel tensor between the two layers is never written or read.
+template <int BN, int NB, int NW = 8, int TS = 32, bool SPLIT = false, bool FUSE1 = false>
 __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh,
                                                         const float *__restrict__ bias, _Float16 *__restrict__ out,
-                                                        const ConvF16Args a, const int lt_rows)
+                                                        const ConvF16Args a, const int lt_rows, const _Float16 *__restrict__ wh2 = nullptr,
+                                                        const float *__restrict__ bias2 = nullptr)
 {
+    static_assert(!FUSE1 || (BN == 256 && NW == 16 && TS == 32 && !SPLIT), "the fused 1x1 is built for the 256-channel, 16-wavefront tile");
     constexpr int BM = 256, BK = 64, ROWH = BK, NT = NW * 64;
     // BN = 128: 4 x 2 wavefronts of 64 x 64, NB = 3 weight-tile buffers;
     // BN = 256: 2 x 4 wavefronts of 128 x 64 (NW = 8) or 4 x 4 of 64 x 64 (NW = 16: four wavefronts per SIMD fill the
@@ -878,6 +885,49 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
                 }
         }
         __syncthreads();
+        if constexpr (FUSE1) {
+            // out2[pixel][32 wn + ...] = sum over the tile's 256 channels; operands swapped (D rows = output channels), so a lane ends up
+            // with 4 consecutive channels of a pixel per register group and v_permlane32_swap pairs the lane halves into 16-byte stores
+            half8_t b2[16];
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) b2[s2] = *reinterpret_cast<const half8_t *>(wh2 + (size_t)(32 * wn + frow) * 256 + 16 * s2 + 8 * fhalf);
+            float16_t acc2[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[i][r] = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const half8_t cf = *reinterpret_cast<const half8_t *>(&Ct[wm * 64 + i * 32 + frow][16 * s2 + 8 * fhalf]);
+                    acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b2[s2], cf, acc2[i], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = q0 + wm * 64 + i * 32 + frow;
+                const bool qok = q < a.npix;
+                _Float16 *orow = out + ((size_t)kLead + flat_of_fast(a, min(q, a.npix - 1))) * a.Cp_out + a.out_ch_off;
+                unsigned pk[4][2];       // [group g = r >> 2][dword]: this lane's channels 8 g + 4 (lane >> 5) .. + 3 of the 32-channel block
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(bias2 + 32 * wn + 8 * g + 4 * fhalf);
+                    float v0 = acc2[i][4 * g + 0] + bv.x, v1 = acc2[i][4 * g + 1] + bv.y, v2 = acc2[i][4 * g + 2] + bv.z, v3 = acc2[i][4 * g + 3] + bv.w;
+                    if (a.leaky) { v0 = fmaxf(v0, v0 * 0.1f); v1 = fmaxf(v1, v1 * 0.1f); v2 = fmaxf(v2, v2 * 0.1f); v3 = fmaxf(v3, v3 * 0.1f); }
+                    const half2_t h01 = {(_Float16)v0, (_Float16)v1}, h23 = {(_Float16)v2, (_Float16)v3};
+                    pk[g][0] = __builtin_bit_cast(unsigned, h01);
+                    pk[g][1] = __builtin_bit_cast(unsigned, h23);
+                }
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                    const uint2v s0 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][0], pk[2 * pr + 1][0], false, false);
+                    const uint2v s1 = __builtin_amdgcn_permlane32_swap(pk[2 * pr][1], pk[2 * pr + 1][1], false, false);
+                    const int c0 = 32 * wn + 8 * (2 * pr + fhalf);
+                    if (qok && c0 < a.n_store) *reinterpret_cast<uint4 *>(orow + c0) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+                }
+            }
+        } else
         if (ch0 < a.n_store) {
 #pragma unroll
             for (int rr = 0; rr < BM / ROWS_PER_PASS; ++rr) {
@@ -2101,8 +2151,10 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
         pel_pk[it] = py | (j << 8) | (c << 16);
         pel_off[it] = row * PCS + 4 * j;
     }
-    float4 pv[NIT];
-    auto request = [&](int tile) {   // clamped addresses (always inside the plane), masked when written
+    // Two tiles' pieces in flight: the set a tile is converted from was requested TWO tiles earlier (one tile ahead left ~0.05 of
+    // 0.19 ms per 128 frames waiting for loads: Y2_C0_ABL = 2).
+    float4 pvA[NIT], pvB[NIT];
+    auto request = [&](int tile, float4 (&pv)[NIT]) {   // clamped addresses (always inside the plane), masked when written
 #if (Y2_C0_ABL & 2)
         tile = (int)blockIdx.x;          // diagnostic: every request re-reads the workgroup's first (cache-hot) patch
 #endif
@@ -2115,8 +2167,10 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             pv[it] = *reinterpret_cast<const float4 *>(fb + ((size_t)(pel_pk[it] >> 16) * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 4));
         }
     };
-    if ((int)blockIdx.x < n_tile_total) request((int)blockIdx.x);
-    for (int tile = (int)blockIdx.x; tile < n_tile_total; tile += (int)gridDim.x) {
+    const int G = (int)gridDim.x;
+    if ((int)blockIdx.x < n_tile_total) request((int)blockIdx.x, pvA);
+    if ((int)blockIdx.x + G < n_tile_total) request((int)blockIdx.x + G, pvB);
+    auto do_tile = [&](int tile, float4 (&pv)[NIT]) {
         const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
 #pragma unroll
@@ -2132,7 +2186,7 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             }
         }
         __syncthreads();   // the patch is complete; everybody has stored the previous tile's pooled rows
-        if (tile + (int)gridDim.x < n_tile_total) request(tile + (int)gridDim.x);
+        if (tile + 2 * G < n_tile_total) request(tile + 2 * G, pv);
 
 #if !(Y2_C0_ABL & 4)
 #pragma unroll
@@ -2170,6 +2224,10 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 32 + ck * 8) =
                 *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
         }
+    };
+    for (int tile = (int)blockIdx.x; tile < n_tile_total; tile += 2 * G) {
+        do_tile(tile, pvA);
+        if (tile + G < n_tile_total) do_tile(tile + G, pvB);
     }
 }
 

@@ -93,7 +93,7 @@ void y2_f16_plan_free(yolo2_hip_ctx *c)
 // fault and an abort inside run_batch_fp16.  This check turns that class of mistake into YOLO2_ERROR before
 // anything is launched; yolo2_hip_f16_store_check exposes it so that it can be tested without a GPU.
 #ifndef Y2_CONV0_WGS
-#define Y2_CONV0_WGS 6
+#define Y2_CONV0_WGS 4
 #endif
 
 static int f16_store_check(const char *kernel, int store, int pool, int B, int H, int W, int Cp_out, int out_ch_off, int n_store,
@@ -233,6 +233,7 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<256, 16, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo_p<128, 8, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_halo<256, 2, 16, 32, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
@@ -305,8 +306,8 @@ template <int BN, int BK> Y2_LAUNCHER(L_reg, hipLaunchKernelGGL((k_conv_f16<128,
                                                                    s.store == FS_REGION ? region : (float *)nullptr, s.a))
 template <int BN, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo_p, hipLaunchKernelGGL((k_conv_f16_halo_p<BN, NW, TS, SP>), s.grid, s.block, s.lds, st, s.in, s.w,
                                                                                             s.bias, s.out, s.a, s.lt_rows, s.T))
-template <int BN, int NB, int NW, int TS, bool SP = false> Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS, SP>), s.grid, s.block, s.lds, st, s.in,
-                                                                                                  s.w, s.bias, s.out, s.a, s.lt_rows))
+template <int BN, int NB, int NW, int TS, bool SP = false, bool F1 = false>
+Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS, SP, F1>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.lt_rows, s.w2, s.bias2))
 template <int MODE> Y2_LAUNCHER(L_rw, hipLaunchKernelGGL((k_conv_f16_rw<13, MODE>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.w2, s.bias2, s.a,
                                                        s.lt_rows, s.T))
 Y2_LAUNCHER(L_maxpool_split, hipLaunchKernelGGL(k_maxpool2_split, s.grid, s.block, 0, st, s.in, s.out, s.oPS, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
@@ -519,6 +520,18 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                         if (wide) {
                             a.n_tiles = l.n / 256;
                             s.grid = dim3(((a.npix + 255) / 256) * a.n_tiles); s.lds = (unsigned)lds256;
+                            // a 256-channel 3x3 whose only consumer is a 1x1 down to 128 channels (layer 8 -> 9): the 1x1 runs in the epilogue
+                            const LayerDesc &nx = kNet[i + 1];
+                            const bool fuse1 = !split && !sw.no_fuse1x1 && !sw.m16 && !sw.w8 && l.n == 256 && a.n_tiles == 1 && nx.type == L_CONV && nx.size == 1 &&
+                                               nx.c == 256 && nx.n == 128 && nx.leaky == l.leaky && nx.h == l.h && nx.w == l.w && i != 16 && i != 24;
+                            if (fuse1) {
+                                const HT &t2 = c->h_out[i + 1];
+                                a.Cp_out = t2.Cp; a.N = nx.n; a.n_store = round_up(nx.n, 32); a.out_ch_off = 0;
+                                s.out = t2.d; dst = &t2; fused_conv = i + 1;
+                                s.w2 = (const _Float16 *)(c->wh + c->wh_off[ord]);          // (ord was advanced above: the NEXT conv's weights)
+                                s.bias2 = (const float *)(c->biasf + c->biasf_off[ord]);
+                                s.kernel = "k_conv_f16_halo<256,2,16>+1x1"; s.launch = L_halo<256, 2, 16, 32, false, true>; s.block = dim3(1024);
+                            } else
                             if (split) { s.kernel = "k_conv_f16_halo<256,2,16,32,split>"; s.launch = L_halo<256, 2, 16, 32, true>; s.block = dim3(1024); }
                             else if (sw.m16) { s.kernel = "k_conv_f16_halo<256,2,16,16>"; s.launch = L_halo<256, 2, 16, 16>; s.block = dim3(1024); }
                             else if (!sw.w8) { s.kernel = "k_conv_f16_halo<256,2,16>"; s.launch = L_halo<256, 2, 16, 32>; s.block = dim3(1024); }   // 16 wavefronts of 64x64 (4 per SIMD, +4 %) instead of 8 of 128x64
