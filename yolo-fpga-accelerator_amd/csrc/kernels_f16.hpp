@@ -1291,17 +1291,28 @@ __global__ __launch_bounds__(256) void k_conv_f16_rw(const _Float16 *__restrict_
     for (int i = tid; i < NBLK * 8 * 8; i += 256) *reinterpret_cast<int4 *>(Zs + (size_t)i * 8) = make_int4(0, 0, 0, 0);
     const int lrow = lane >> 3, lslot = lane & 7;
     const int n_stage = (2 * a.W + 2 * (a.W + 1) + 7) / 8;     // 8-row groups that hold real pixels
+    // Staging sources, once per kernel: LDS row R of a tile is pixel p = R - (W + 1) relative to the tile's first pixel (b, y0, 0), i.e.
+    // image row y0 + floor(p / W), column p mod W - the same for every tile, so a lane keeps the BYTE offset of each of its pieces
+    // relative to item (b, y0, 0) (swizzled 16-byte chunk included) and a fill is one add per piece.  (Recomputing the pixel -> item
+    // map per piece - two multiply-high divisions - was ~25 instructions x 14 pieces per tile in front of every tile's first MFMA.)
+    // No clamping: the rows above image 0 / below the last image fall into the tensor's lead / tail items (kLead, kTail) and are only
+    // ever read masked.
+    constexpr int kMaxFill = (4 * 8 * NBLK + 2 + 7) / 8 / 4 + 1;
+    int relb[kMaxFill];
+#pragma unroll
+    for (int it = 0; it < kMaxFill; ++it) {
+        const int row = (wave + 4 * it) * 8 + lrow, pp = row - (a.W + 1) + 2 * a.W;      // >= 0
+        const int ry = pp / a.W - 2, x = pp - (ry + 2) * a.W;
+        relb[it] = (ry * a.Wp + x) * 128 + ((lslot ^ rw_swz(row)) * 16);
+    }
     auto fill_a = [&](int ti) {                 // the halo tile of this workgroup's ti-th tile -> buffer ti & 1
         const int t = t_first + ti * S, b = t / HH, y0 = 2 * (t - b * HH);
-        const int d0 = (b * a.H + y0) * a.W - a.W - 1;
+        const int base = (kLead + b * a.PL + (y0 + 1) * a.Wp) * 128;      // byte offset of item (b, y0, 0); the tensor stays below 2 GiB (host check)
         const char *abase = reinterpret_cast<const char *>(act);
-        int lr = lrow, ls = lslot;
-        asm volatile("" : "+v"(lr), "+v"(ls));
-        for (int g = wave; g < n_stage; g += 4) {
-            const int row = g * 8 + lr;
-            const int d = min(max(d0 + row, 0), a.npix - 1);     // rows outside the tensor are only ever read masked
-            const unsigned src = ((unsigned)(kLead + flat_of_fast(a, d)) * 64u + (unsigned)((ls ^ rw_swz(row)) * 8)) * 2u;
-            lds_dma16(abase, src, As + ((size_t)(ti & 1) * lt_rows + g * 8) * ROWH);
+#pragma unroll
+        for (int it = 0; it < kMaxFill; ++it) {
+            const int g = wave + 4 * it;
+            if (g < n_stage) lds_dma16(abase, (unsigned)(base + relb[it]), As + ((size_t)(ti & 1) * lt_rows + g * 8) * ROWH);
         }
     };
 

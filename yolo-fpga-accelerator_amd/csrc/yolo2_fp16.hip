@@ -413,7 +413,8 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             // The 64 -> 128 channel 3x3 layers at 104 x 104 (4 and 6): weights resident in registers, two image rows per tile, one barrier
             // per tile (k_conv_f16_rw).  Layer 6 fuses its pool (MODE 1); layer 4 fuses the 1x1 layer 5, its only consumer (MODE 2:
             // the 128-channel tensor between them is never written); MODE 0 stores the plain tensor.
-            if (!done && !split && !sw.no_rw && l.size == 3 && a.Cp_in == 64 && l.n == 128 && l.w == 8 * 13 && (l.h & 1) == 0 && in32 && !sw.no_glds) {
+            if (!done && !split && !sw.no_rw && l.size == 3 && a.Cp_in == 64 && l.n == 128 && l.w == 8 * 13 && (l.h & 1) == 0 && !sw.no_glds &&
+                ((size_t)kLead + (size_t)B * a.PL + kTail) * 128 < (1ull << 31)) {   // (signed 32-bit byte offsets into the input)
                 const bool pool_here = kNet[i + 1].type == L_MAX && !sw.no_poolfuse;
                 const LayerDesc &nx = kNet[i + 1];
                 const bool fuse1 = !pool_here && !sw.no_fuse1x1 && nx.type == L_CONV && nx.size == 1 && nx.c == 128 && nx.n == 64 && nx.leaky == l.leaky &&
