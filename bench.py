@@ -271,6 +271,24 @@ def box_iou_vs_reference(gpu_region, ref_region, obj_thresh=0.3):
             "note": f"all 845 cell/anchor slots of frame 0 (640x480 image geometry), same slot in both tensors; confident = reference objectness > {obj_thresh}"}
 
 
+MFMA_BUSY_FILE = os.path.join("profiles", "r04_f16_mfma_busy.json")
+
+
+def fp16_mfma_busy():
+    """Per-kernel MFMA-busy of the fp16 pass (PMC counters cannot be collected from inside this process): tools/pmc.sh + tools/mfma_busy.py
+    commit it under profiles/ with the hash of csrc/kernels_f16.hpp; a file taken on other kernels is not reported."""
+    import hashlib
+    try:
+        doc = json.load(open(os.path.join(ROOT, MFMA_BUSY_FILE)))
+    except (OSError, ValueError):
+        return {"source": f"{MFMA_BUSY_FILE} not present"}
+    h = hashlib.sha256(open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "kernels_f16.hpp"), "rb").read()).hexdigest()[:16]
+    if doc.get("kernels_f16_hash") != h:
+        return {"source": f"{MFMA_BUSY_FILE} was measured on other kernels ({doc.get('kernels_f16_hash')}): re-run tools/pmc.sh + tools/mfma_busy.py"}
+    return {"source": MFMA_BUSY_FILE, "definition": doc["what"],
+            "per_kernel": {k: v["mfma_busy"] for k, v in doc["kernels"].items() if v["mfma_busy"] > 0}}
+
+
 def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     """Roofline objects of the fp16 MFMA path from one timed run: `dt` seconds for `steps` passes over B frames per GPU,
     layer_ms = the library's per-layer hipEvent times of lane 0 (overlapped with the other lane's launches), solo_ms = the same
@@ -280,7 +298,8 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
         solo_ms = solo_ms[0]
     Bl = B // lanes
     conv_ms = float(sum(layer_ms[l.idx] for l in net.CONVS))
-    halo = [l for l in net.CONVS if l.size == 3 and l.w <= 52 and l.n % 128 == 0 and l.c % 64 == 0]
+    kern = ctx.fp16_layer_kernels()       # the launch table says which layers the dominant kernel runs (layer 8 runs it with layer 9 fused in: not counted)
+    halo = [l for l in net.CONVS if kern.get(l.idx, "").startswith("k_conv_f16_halo<") and "+1x1" not in kern[l.idx]]
     halo_flops = 2.0 * Bl * sum(l.size * l.size * l.c * l.n * l.out_h * l.out_w for l in halo)
     halo_ms = float(sum((solo_ms if solo_ms is not None else layer_ms)[l.idx] for l in halo))
     halo_ach = halo_flops / (halo_ms * 1e-3) / 1e12             # solo: the launch has the chip to itself, no extrapolation
@@ -291,9 +310,10 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     return {
         "value": world * B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16",
         "config": {"workload": f"YOLOv2 fp16 416x416 batch={B} per GPU, MFMA implicit-GEMM conv (fp32 accumulate)",
-                   "batch_per_gpu": B, "global_batch": B * world, "lanes": lanes, "frames_per_launch": Bl},
-        # dominant kernel: k_conv_f16_halo (3x3 layers at <= 52x52 with >= 128 output channels; selection rule of
-        # yolo2_hip_run_batch_fp16) - its layers' FLOPs / their hipEvent time; whole_pass = all conv layers (incl. fused pools)
+                   "batch_per_gpu": B, "global_batch": B * world, "lanes": lanes, "frames_per_launch": Bl,
+                   "kernels": {str(i): k for i, k in sorted(kern.items())}},
+        # dominant kernel: k_conv_f16_halo (3x3 layers at <= 52x52 with >= 128 output channels, as the launch table reports them)
+        # - its layers' FLOPs / their hipEvent time; whole_pass = all conv layers (incl. fused pools and fused 1x1 layers)
         "roofline": {"bound": "mfma", "kernel": "k_conv_f16_halo", "launches_per_step": len(halo), "layers": [l.idx for l in halo],
                      "avg_launch_ms": halo_ms / len(halo), "achieved": halo_ach, "peak": MFMA_PEAK_TFLOPS,
                      "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": None,
@@ -306,6 +326,7 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
         # chip level, independent of how the lanes' launches overlap: all conv FLOPs of the step / wall time of the step
         "whole_pass": {"scope": "all conv FLOPs of one step (both lanes) / ms_per_step", "achieved": chip_ach, "unit": "TFLOP/s",
                        "frac": chip_ach / MFMA_PEAK_TFLOPS},
+        "mfma_busy": fp16_mfma_busy(),
         "layer_ms": [round(float(x), 4) for x in layer_ms], "conv_ms_per_step": conv_ms,
     }
 
@@ -365,7 +386,7 @@ def bench_fp16(args, world, rank, local_rank, dev):
         result = {"metric": "YOLOv2 fp16 416x416 frames/sec", "value": rec["value"], "unit": "frames/s", "n_gpus": world,
                   "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"],
                   "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic"}
-        result.update({k: rec[k] for k in ("config", "roofline", "whole_pass", "layer_ms", "conv_ms_per_step")})
+        result.update({k: rec[k] for k in ("config", "roofline", "whole_pass", "mfma_busy", "layer_ms", "conv_ms_per_step")})
         if rccl is not None:
             result["rccl"], result["per_rank"] = rccl, per_rank
         if world == 1 and not args.no_cpu_baseline:

@@ -1243,3 +1243,21 @@ def test_f32tol_mfma_path_every_box_within_1e_3_of_the_fp32_reference():
     for k in (0, 1, 33, 63):
         assert np.array_equal(rb[k], region[k % 5]), k
     ctx.close()
+
+
+@pytest.mark.parametrize("qset", ["std", "varq"])
+def test_fullnet_sixteen_groups_per_barrier_on_1x1_layers(qset, monkeypatch):
+    """Option grp16 (round 4): the 1x1 layers stage and consume SIXTEEN channel groups per workgroup barrier
+    instead of eight (k_conv_i16<1, P, MODE, 8, 16>).  Same chain per output, so the same bits: batch 3 and a 22-frame lane's
+    batch against the reference fixture, both Q sets."""
+    monkeypatch.setenv("YOLO2_GRP16", "1")
+    model = synth.SynthModel(seed=1, **_qsets()[qset])
+    frames = np.concatenate([synth.frames(7, 1), synth.frames(300, 21)])
+    ctx = hipdrv.Yolo2Hip(0)
+    assert ctx.options() == "grp16=1"
+    ctx.load_model(model)
+    for batch in (3, 22):
+        region, _ = ctx.run_batch_host(frames[:batch])
+        assert any("grp=16" in ctx.conv_plan(l.ord) for l in net.CONVS if l.size == 1), [ctx.conv_plan(l.ord) for l in net.CONVS if l.size == 1]
+        assert np.array_equal(region[0].reshape(-1), FULL[f"i16/{qset}/region_raw_i16"]), batch
+    ctx.close()

@@ -62,7 +62,7 @@ struct Y2Options {
     // (b)
     int splitk = -1;              // -1 tuned; 0 no K-split of either kind; 1 the lane-split kernel wherever legal
     int poolfuse = -1;            // 1: conv + pool fused wherever legal
-    bool no_poolfuse = false, no_hiacc = false, no_ks = false, no_w16 = false, no_grp = false, no_xcd_remap = false, splitk_no_pack = false;
+    bool no_poolfuse = false, no_hiacc = false, no_ks = false, no_w16 = false, no_grp = false, grp16 = false, no_xcd_remap = false, splitk_no_pack = false;
     int f16_lanes = 2;
     bool f16_no_lanes = false, f16_no_mfma0 = false, f16_no_glds = false, f16_no_poolfuse = false, f16_no_halo = false, f16_no_persist = false,
          f16_persist_all = false, f16_ring_all = false, f16_no_ring = false, f16_no_c32 = false, f16_m16 = false, f16_w8 = false, f16_no_wide = false,
@@ -81,7 +81,7 @@ struct Y2Options {
     // the settings that differ from the defaults, "name=value name=value" ("" if none): what bench.py discloses
     std::string describe() const;
     // switches that ask for a plan the committed table / the weight cache do not hold: those are bypassed
-    bool steered() const { return splitk >= 0 || poolfuse >= 0 || no_poolfuse || no_w16 || no_hiacc || no_ks || no_grp || no_xcd_remap; }
+    bool steered() const { return splitk >= 0 || poolfuse >= 0 || no_poolfuse || no_w16 || no_hiacc || no_ks || no_grp || no_xcd_remap; }   // (grp16 keeps the plan sources: it changes no plan field)
 };
 const Y2Options &y2_process_options();   // from the environment, parsed once: the context-less driver tier and process-wide latches
 

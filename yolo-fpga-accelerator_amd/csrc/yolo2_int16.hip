@@ -129,6 +129,8 @@ static void plan_conv(ConvPlan &p, const ActGeom &gin, long out_cg_stride, long 
     if (p.w16) p.lds_pad = 0;
     if (p.hiacc && (p.path != 4 || p.splitk || p.w16 || p.P > 4)) p.hiacc = 0;   // (8 pixels per lane x 8 accumulators does not leave room for the rest)
     p.grp = (!p.splitk && p.K == 1 && p.path != 2 && gin.CG % 8 == 0 && a.lt_max * 8 <= kMaxTileItems && !opt.no_grp) ? 8 : 1;
+    // (option grp16, A/B: sixteen channel groups per barrier - twice the steps between two barriers of a 1x1 layer)
+    if (p.grp == 8 && opt.grp16 && gin.CG % 16 == 0 && a.lt_max * 16 <= kMaxTileItems && p.P <= 2 && (p.path == 3 || p.path == 4) && !p.hiacc) p.grp = 16;
     // (two channel groups per barrier for the 3x3 forms C/D - one barrier per 18 taps - was measured: -1 to -2 %)
     p.lds_bytes = p.splitk ? p.splitk * (a.lt_max + p.K * p.K * 32 + 4) * 8 * 2 : std::max(a.lt_max * p.grp * 8 * 2, p.lds_pad);  // double-buffered input tile (or the occupancy cap)
     p.grid = dim3((npix + T - 1) / T, p.mb_count ? p.mb_count : (p.N + 31) / 32, 1);
@@ -205,6 +207,10 @@ template <int KS, int MODE, int P>
 static void launch_conv_n(const ConvPlan &p, const int2 *in, int2 *out, const int2 *wpk, const short *bias, hipStream_t st)
 {
     const int nst = (p.args.lt_max * p.grp + 255) / 256;
+    if (KS == 1 && p.grp == 16 && (MODE == 3 || MODE == 4) && P <= 2) {
+        hipLaunchKernelGGL((k_conv_i16<1, (P <= 2 ? P : 1), (MODE == 3 || MODE == 4) ? MODE : 3, 8, KS == 1 ? 16 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
+        return;
+    }
     if (KS == 1 && p.grp == 8 && MODE != 2) {
         if (nst <= 4) hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 4, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);
         else hipLaunchKernelGGL((k_conv_i16<1, P, MODE == 2 ? 1 : MODE, 8, KS == 1 ? 8 : 1>), p.grid, dim3(256), p.lds_bytes, st, in, out, wpk, bias, p.args);

@@ -25,7 +25,7 @@ struct StrOpt { const char *name; std::string Y2Options::*m; };
 const FlagOpt kFlags[] = {
     {"no_lanes", &Y2Options::no_lanes}, {"verbose", &Y2Options::verbose}, {"no_plan_cache", &Y2Options::no_plan_cache},
     {"no_poolfuse", &Y2Options::no_poolfuse}, {"no_hiacc", &Y2Options::no_hiacc}, {"no_ks", &Y2Options::no_ks},
-    {"no_w16", &Y2Options::no_w16}, {"no_grp", &Y2Options::no_grp}, {"no_xcd_remap", &Y2Options::no_xcd_remap},
+    {"no_w16", &Y2Options::no_w16}, {"no_grp", &Y2Options::no_grp}, {"grp16", &Y2Options::grp16}, {"no_xcd_remap", &Y2Options::no_xcd_remap},
     {"splitk_no_pack", &Y2Options::splitk_no_pack}, {"force_w16", &Y2Options::force_w16}, {"force_hiacc", &Y2Options::force_hiacc},
     {"f16_no_lanes", &Y2Options::f16_no_lanes}, {"f16_no_mfma0", &Y2Options::f16_no_mfma0}, {"f16_no_glds", &Y2Options::f16_no_glds},
     {"f16_no_poolfuse", &Y2Options::f16_no_poolfuse}, {"f16_no_halo", &Y2Options::f16_no_halo}, {"f16_no_persist", &Y2Options::f16_no_persist},
