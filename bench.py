@@ -94,8 +94,7 @@ def cpu_baseline(model, frames, gpu_regions):
         regions = [_ref_forward_one(orclib, model, frames[0])]      # ONE frame (about 6.5 s): keeps the default run short
         dt = time.perf_counter() - t0
         out = {"value": 1 / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
-               "sample": "ONE frame, one timing sample (6.5 s; a median of three would triple the default run): 23 conv + 5 maxpool layers "
-                         "through the reference's own YOLO2_FPGA (oracle/_ref, built from the reference sources), single thread, weights in memory",
+               "sample": "1 frame, 1 sample: 23 conv + 5 maxpool through the reference's own YOLO2_FPGA (oracle/_ref), 1 thread",
                "seconds_per_frame": dt}
     else:
         orclib.oracle().orc_set_threads(1)
@@ -116,7 +115,7 @@ def cpu_baseline(model, frames, gpu_regions):
     mt = [orclib.forward_i16(model, f)[0] for f in frames]
     dt = time.perf_counter() - t0
     out["all_cores"] = {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-                        "sample": f"{n} frames (first and last of the batch) through oracle/yolo2_oracle.c, {cores} OpenMP threads",
+                        "sample": f"{n} frames, oracle/yolo2_oracle.c, {cores} OpenMP threads",
                         "matches_single_thread_reference": bool(np.array_equal(np.asarray(mt[0]).reshape(-1), np.asarray(regions[0]).reshape(-1))),
                         "gpu_matches_bit_exact": bool(all(np.array_equal(np.asarray(a).reshape(-1), g.reshape(-1))
                                                           for a, g in zip(mt, gpu_regions)))}

@@ -3,5 +3,5 @@
 P=$PWD/yolo-fpga-accelerator_amd/build
 for v in "" 1 2 4 7; do
   L=${v:+$P/lib_c0abl$v.so}
-  echo "== Y2_C0_ABL=${v:-0}"; YOLO2_HIP_LIB=$L YOLO2_F16_NO_IM2COL0=1 python3 tools/f16_layers.py 128 10 2>/dev/null | grep "^L 0"
+  echo "== Y2_C0_ABL=${v:-0}"; YOLO2_HIP_LIB=$L python3 tools/f16_layers.py 128 10 2>/dev/null | grep "^L 0"
 done

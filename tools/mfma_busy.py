@@ -5,7 +5,7 @@ fp16 record: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 
 kernel's own run time in which the matrix pipe is occupied (dispatches are serialised under counter collection: every launch has the
 chip to itself).  The file carries the hash of csrc/kernels_f16.hpp; bench.py ignores it when the kernels have changed since.
 usage: python3 tools/mfma_busy.py gpurun_out/pmc_<tag> profiles/<name>.json"""
-import collections, csv, glob, hashlib, json, os, subprocess, sys
+import collections, csv, glob, hashlib, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d, out = sys.argv[1], sys.argv[2]
 path = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
@@ -16,10 +16,17 @@ for r in csv.DictReader(open(path)):
     if r["Dispatch_Id"] not in seen:
         seen.add(r["Dispatch_Id"]); calls[k] += 1
 def demangle(n):
-    try:
-        return subprocess.run(["c++filt", n], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
-    except OSError:
-        return n
+    """y2:: kernel names without a demangler that knows _Float16 (DF16_): _ZN2y2<len><name>[I<args>E]... -> name<args>"""
+    m = re.match(r"_ZN2y2(\d+)", n)
+    if not m:
+        return n.split("(")[0].replace("void ", "")
+    ln = int(m.group(1)); name = n[m.end():m.end() + ln]; rest = n[m.end() + ln:]
+    if rest.startswith("I"):
+        args = re.findall(r"L([ib])(n?\d+)E", rest[:rest.index("EE") + 1] if "EE" in rest else rest)
+        name += "<" + ",".join(("true" if v == "1" else "false") if t == "b" else v.replace("n", "-") for t, v in args) + ">"
+    return "y2::" + name
+
+
 rows = {}
 for k, v in agg.items():
     if v.get("GRBM_GUI_ACTIVE", 0) <= 0 or "y2" not in k:

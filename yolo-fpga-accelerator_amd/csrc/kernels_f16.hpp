@@ -1253,11 +1253,6 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo_p(const _Float16 *__r
 //              52 more MFMAs per wavefront (its 16 of the 64 output channels, weights again in registers) and 8-byte stores of layer
 //              5's tensor.  Same bits as the two-kernel route's fp16 intermediate.
 // K order tap-major like k_conv_f16; operands fp16, accumulate fp32.  wh: [N][9][64] halves; wh2 (MODE 2): [64][1][128].
-// LDS slot swizzle of k_conv_f16_rw's input tile.  A v_mfma_f32_16x16x32_f16 fragment read puts lanes of TWO k-groups (kq, kq + 1:
-// slots s and s ^ 1) into one 16-lane ds_read_b128 group, on the rows {+0,1,104,105,6,7,110,111} and {+2,3,106,107,4,5,108,109} of
-// the window ordering; the halo kernels' key (row >> 1) & 7 makes those two sets meet on the same bank slots for every second tile
-// base (2-way conflicts: the reads of a tile then take as long as its MFMAs).  This key only moves slot bits 1-2 - the k-group parity
-// keeps the two sets apart - and is conflict-free for every base row, both channel halves and both lane-group shapes (brute-forced).
 #ifndef Y2_RW_ABL
 #define Y2_RW_ABL 0         // diagnostic builds of k_conv_f16_rw: 2 = no fragment reads, 4 = no epilogue, 8 = no input staging
 #endif
