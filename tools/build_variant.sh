@@ -10,6 +10,7 @@ NAME=$1; TU=$2; shift; shift
 P=$(cd "$(dirname "$0")/.." && pwd)/yolo-fpga-accelerator_amd
 make -s -C "$P" -j6 "$P/libyolo2_hip.so" >/dev/null
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-function -ffp-contract=off -fno-slp-vectorize"
+[ "$TU" = yolo2_fp16 ] && FLAGS="$FLAGS -mllvm -amdgpu-mfma-vgpr-form"     # (the Makefile's TUFLAGS_yolo2_fp16)
 /opt/rocm/bin/hipcc $FLAGS "$@" -c -o "$P/build/${TU}_$NAME.o" "$P/csrc/$TU.hip"
 OBJS=""
 for t in yolo2_hip yolo2_driver yolo2_plan yolo2_int16 yolo2_fp16 yolo2_fp32 yolo2_multi yolo2_post; do

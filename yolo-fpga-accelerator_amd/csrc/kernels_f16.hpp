@@ -1533,6 +1533,359 @@ __global__ __launch_bounds__(256) void k_conv_f16_rw(const _Float16 *__restrict_
     }
 }
 
+// ---- k_conv_f16_rwb: k_conv_f16_rw with its epilogue INSIDE the MFMA stream --------------------------------------------------
+// k_conv_f16_rw multiplies a tile tap by tap with all 26 accumulators live and runs the epilogue afterwards, with one wavefront per
+// SIMD and nothing to cover it: tools/rw_abl.sh prices that at 0.033 ms of layer 6's 0.176 (pool) and 0.113 ms of layers 4 + 5's
+// 0.267 (intermediate tile, second GEMM, stores) per 128 frames, against 0.13 ms of MFMA issue.  Here the order is BLOCK-outer:
+// the weights are in registers anyway, so one block of 16 pixels is finished (18 fragments x 2 channel blocks = 36 MFMAs) before
+// the next begins, only two pairs of accumulators exist, and a finished block's epilogue is cut into pieces of <= 3 VALU
+// instructions that are placed, one per MFMA, between the NEXT block's MFMAs (a 16x16x32 MFMA holds the issue port for half of its
+// 16 cycles).  Every slot ends in a sched_barrier, so the order written here is the order issued.
+//   * the input tile is staged WITH the layout's zero columns and rows (layout.hpp: out-of-image taps read stored zeros): four image
+//     rows of 108 LDS rows each - x = -1 (the zero column before the row), x = 0 .. 103, x = 104 (the zero column after it), two unused -
+//     so there is no zero region and no mask.  The pitch is 108 because of the swizzle: at 105 (the tensor's own pitch) no XOR key
+//     over the row bits makes the 16x16x32 fragment reads conflict-free (best 2-way; (row >> 1) & 7 is 3-way and the kernel ran at
+//     the speed of its LDS reads); at 108 the key {bit 1 -> slot bit 2, bit 2 -> slot bit 1} is conflict-free for every tap, both
+//     channel halves and all four lane groups of ds_read_b128 (brute force over the bank model of MI355X_MICROARCH.md);
+//   * MODE 1 (layer 6 + pool): block b's pooled values go to the LDS tile during block b + 1; the pooled row of tile t - 1 is
+//     stored during block 0 of tile t;
+//   * MODE 2 (layer 4 + layer 5): the leaky'd fp16 result T [208][128] has its own LDS region (XOR-swizzled 256-byte rows) and the
+//     tile is worked in two halves (blocks 0-6 | 7-12) with a barrier between: while one half is multiplied, the 1x1 of the OTHER
+//     half - written before the last barrier - runs from T (4 fragment reads, 4 MFMAs, bias + leaky + 8-byte stores per block),
+//     also between the 3x3's MFMAs.  Two barriers per tile; T-writes of a half's last block and one 1x1 block are all that is
+//     exposed.
+// Same arithmetic and the same bits as k_conv_f16_rw (bias after the sum, leaky as max(v, 0.1 v), fp16 intermediate).
+// Host: W = 104, 64-channel items in, leaky layers, every channel stored (build_f16_plan).
+#ifndef Y2_RWB_ABL
+#define Y2_RWB_ABL 0        // diagnostic builds of k_conv_f16_rwb (results wrong, only time matters): 1 = no per-group LDS waits, 2 = no staging,
+#endif                      // 4 = no epilogue work between the MFMAs, 8 = no fragment reads
+template <int MODE>
+__global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh, const float *__restrict__ bias,
+                                                       _Float16 *__restrict__ out, const _Float16 *__restrict__ wh2, const float *__restrict__ bias2,
+                                                       const ConvF16Args a, const int n_tile_total)
+{
+    static_assert(MODE == 1 || MODE == 2, "pool or fused 1x1");
+    constexpr int NBLK = 13, WP = 8 * NBLK + 1, LP = 108, ROWH = 64, PD = 6, NF = NBLK * 18, NG = NF / PD, H0 = 7;
+    constexpr int LT = 4 * LP, kPieces = LT / 8, kFill = (kPieces + 3) / 4;   // 432 LDS rows per tile = 54 staged 8-row groups, 14 per wavefront
+    constexpr int kCtP = 136;                                    // halves per row of the pooled tile (MODE 1)
+    constexpr unsigned kBufBytes = LT * ROWH * 2, kCtBytes = (NBLK * 4) * kCtP * 2;
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    _Float16 *As = smem_h;                                       // [2][LT][64]
+    _Float16 *Xs = smem_h + (size_t)2 * LT * ROWH;               // MODE 1: pooled tiles [2][52][kCtP]; MODE 2: T [208][128], swizzled
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HH = a.H >> 1;
+    const int xcd = (int)blockIdx.x & 7, S = (int)gridDim.x >> 3;
+    const int t_first = (int)((long)n_tile_total * xcd / 8) + ((int)blockIdx.x >> 3);
+    const int t_end = (int)((long)n_tile_total * (xcd + 1) / 8);
+    const int my_n = t_first < t_end ? (t_end - t_first + S - 1) / S : 0;
+    if (my_n == 0) return;
+
+    // ---- staging: LDS row R = image row y0 - 1 + R / 108, x = R % 108 - 1; 16-byte chunks XOR-swizzled by rkey(R)
+    auto rkey = [](int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1); };
+    const int lrow = lane >> 3, lslot = lane & 7;
+    // (piece wave + 4 it; the three wavefronts whose fourteenth piece would lie past the tile stage piece 52 again - the same bytes -
+    //  so that no fill is conditional: a branch would end the basic block and with it the slot order the sched_barriers pin)
+    int relb[kFill];                             // source byte offset of this lane's chunk relative to item (b, y0 - 1, 0)
+#pragma unroll
+    for (int it = 0; it < kFill; ++it) {
+        const int row = min(wave + 4 * it, kPieces - 1) * 8 + lrow, ir = row / LP, c = row - ir * LP;
+        relb[it] = (ir * WP + c - 1) * 128 + ((lslot ^ rkey(row)) * 16);
+    }
+    const char *abase = reinterpret_cast<const char *>(act);
+    auto tile_item = [&](int ti) -> int {        // item index of (b, y0, 0) of this workgroup's ti-th tile
+        const int t = t_first + ti * S, b = t / HH, y0 = 2 * (t - b * HH);
+        return kLead + b * a.PL + (y0 + 1) * WP;
+    };
+    int fill_base = 0;                           // byte offset of item (b, y0 - 1, 0) of the tile being staged
+    auto fill_piece = [&](int ti, int it) {
+        const int g = min(wave + 4 * it, kPieces - 1);
+        lds_dma16(abase, (unsigned)(fill_base + relb[it]), As + ((size_t)(ti & 1) * LT + g * 8) * ROWH);
+    };
+
+    // ---- resident weights: lane (i = lane & 15, kq = lane >> 4) holds k = 8 kq .. 8 kq + 7 of row / column i of every fragment
+    const int mi = lane & 15, kq = lane >> 4;
+    half8_t bfr[18][2];
+#pragma unroll
+    for (int s = 0; s < 18; ++s)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            bfr[s][cb] = *reinterpret_cast<const half8_t *>(wh + ((size_t)(32 * wave + 16 * cb + mi) * 9 + (s >> 1)) * 64 + 32 * (s & 1) + 8 * kq);
+    half8_t b2fr[MODE == 2 ? 4 : 1];
+    if constexpr (MODE == 2) {
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) b2fr[s2] = *reinterpret_cast<const half8_t *>(wh2 + (size_t)(16 * wave + mi) * 128 + 32 * s2 + 8 * kq);
+    }
+    // this lane's pixel inside a block: MFMA row / column mi = 4 (window in block) + 2 dy + dx
+    const int dy = (mi >> 1) & 1, dx = mi & 1, pw = mi >> 2;
+    const int lo0 = dy * LP + 2 * pw + dx;        // LDS row of tap (0, 0), block 0 (block k: + 8 k rows = + 1024 k bytes, the instruction's immediate)
+    const unsigned as_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)As;
+    const unsigned xs_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)Xs;
+    // A fragment (tap, channel half h, block k): row r0 + 8 k, whose key is key(r0) (the key reads row bits 1-2 only): byte address
+    // e[tap] ^ 64 h, + 1024 k
+    unsigned erel[9], ecur[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int r0 = lo0 + (tap / 3) * LP + (tap % 3);
+        erel[tap] = as_lds + (unsigned)(r0 * 128 + ((kq ^ rkey(r0)) * 16));
+    }
+
+    // ---- epilogue constants
+    float bv1[2];                                 // MODE 1: bias of this lane's channel in each channel block
+    acc_t bv2[2], b2v;                            // MODE 2: bias of this lane's 4 channels per channel block; of its 4 output channels of the 1x1
+    unsigned ctw[2], twr[2], trb = 0, ct_cur[2] = {0, 0};
+    unsigned o_lane = 0;                          // MODE 2: byte offset of this lane's pixel / channels relative to item (b, y0, 0) of the 1x1's tensor
+    if constexpr (MODE == 1) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            bv1[cb] = bias[32 * wave + 16 * cb + mi];
+            ctw[cb] = xs_lds + (unsigned)((kq * kCtP + 32 * wave + 16 * cb + mi) * 2);      // pooled pixel 4 k + kq, channel
+        }
+    } else {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias + 32 * wave + 16 * cb + 4 * kq);
+            bv2[cb] = acc_t{b4.x, b4.y, b4.z, b4.w};
+            // T row 16 k + mi, channels 32 wave + 16 cb + 4 kq .. + 3: 16-byte slot (4 wave + 2 cb + (kq >> 1)) ^ mi, upper or lower 8 bytes
+            twr[cb] = xs_lds + (unsigned)(mi * 256 + (((4 * wave + 2 * cb + (kq >> 1)) ^ mi) * 16) + (kq & 1) * 8);
+        }
+        const float4 b4 = *reinterpret_cast<const float4 *>(bias2 + 16 * wave + 4 * kq);
+        b2v = acc_t{b4.x, b4.y, b4.z, b4.w};
+        trb = xs_lds + (unsigned)(mi * 256 + ((kq ^ mi) * 16));       // fragment of k-slice s2: slot (4 s2 + kq) ^ mi = byte address ^ 64 s2
+        o_lane = (unsigned)((((dy * WP + 2 * pw + dx) * a.Cp_out) + a.out_ch_off + 16 * wave + 4 * kq) * 2);
+    }
+
+    half8_t fr[2][PD];
+    acc_t acc[2][2];
+    // MODE 2 state carried between slots
+    acc_t acc2[2];
+    half8_t tf[2][4];
+    float tv[2][4], tu[2][4], ov[4], ou[4];
+    unsigned tpk[2][2], opk[2];
+    // MODE 1 state
+    float pm[2], pt[2];
+    unsigned ph[2];
+    half8_t pst[4];
+    char *o_cur = nullptr, *o_prev = nullptr;    // MODE 2: item (b, y0, 0) of the 1x1's tensor for this / the previous tile; MODE 1: pooled row of the previous tile
+
+    auto issue_a = [&](int g, int i) {
+        const int F = g * PD + i, blk = F / 18, s = F % 18;
+#if (Y2_RWB_ABL & 8)
+        asm volatile("v_mov_b32 %0, %1" : "=v"(fr[g & 1][i][0]) : "v"(ecur[s >> 1]) : "memory");
+        return;
+#endif
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[g & 1][i]) : "v"(ecur[s >> 1] ^ (unsigned)(64 * (s & 1))), "i"(blk * 1024) : "memory");
+    };
+    auto leaky = [](float v) { return fmaxf(v, v * 0.1f); };      // == (v < 0 ? 0.1 v : v), one instruction less
+    auto pack2 = [](float x, float y) -> unsigned { const half2_t h = {(_Float16)x, (_Float16)y}; return __builtin_bit_cast(unsigned, h); };
+
+    // ---- the epilogue as MICRO-OPS (one VALU instruction or one memory access each).  A 16x16x32 MFMA holds the issue port for 8 of its
+    // 16 cycles and a VALU instruction for 4: a slot carries its MFMA and at most TWO micro-ops; the first three slots of a group carry
+    // the next group's six fragment reads instead.  So a block of 36 slots has 27 free slots = 54 micro-op positions k.
+    // MODE 1, block pb: positions 0..5 / 6..11 (channel blocks 0 / 1): pool = max over the four registers (one window), bias, leaky,
+    // convert; 18 / 19: the 2-byte LDS writes (early in the next group: an LDS access must be old at the wait that ends its group)
+    auto drain1 = [&](int pb, int k) {
+        const int set = pb & 1;
+        if (k < 12) {
+            const int cb = k / 6, j = k % 6;
+            if (j == 0) pm[cb] = fmaxf(fmaxf(acc[set][cb][0], acc[set][cb][1]), acc[set][cb][2]);
+            else if (j == 1) pm[cb] = fmaxf(pm[cb], acc[set][cb][3]);
+            else if (j == 2) pm[cb] = pm[cb] + bv1[cb];
+            else if (j == 3) pt[cb] = pm[cb] * 0.1f;
+            else if (j == 4) pm[cb] = fmaxf(pm[cb], pt[cb]);         // leaky == (v < 0 ? 0.1 v : v)
+            else ph[cb] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)pm[cb]);
+        } else if (k == 18 || k == 19) {
+            const int cb = k - 18;
+            asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(ct_cur[cb]), "v"(ph[cb]), "i"(4 * pb * kCtP * 2) : "memory");
+        }
+    };
+    // bias + leaky + fp16 of four accumulator values in 14 micro-ops: v[4] in, two packed registers out
+    auto epi14 = [&](int j, const acc_t &v, const acc_t &bv, float (&t)[4], float (&u)[4], unsigned (&pk)[2]) {
+        const int r = j < 7 ? j / 3 : 2 + (j - 7) / 3, ph3 = j < 7 ? j % 3 : (j - 7) % 3;
+        if (j == 6) pk[0] = pack2(t[0], t[1]);
+        else if (j == 13) pk[1] = pack2(t[2], t[3]);
+        else if (ph3 == 0) t[r] = v[r] + bv[r];
+        else if (ph3 == 1) u[r] = t[r] * 0.1f;
+        else t[r] = fmaxf(t[r], u[r]);
+    };
+    // MODE 2, T-write of block pb: positions 4..17 / 20..33 the values of channel blocks 0 / 1, 18 / 36 their 8-byte LDS writes
+    auto drain2 = [&](int pb, int k) {
+        const int set = pb & 1;
+        if (k >= 4 && k < 18) epi14(k - 4, acc[set][0], bv2[0], tv[0], tu[0], tpk[0]);
+        else if (k >= 20 && k < 34) epi14(k - 20, acc[set][1], bv2[1], tv[1], tu[1], tpk[1]);
+        else if (k == 18 || k == 36) {
+            const int cb = k == 18 ? 0 : 1;
+            const uint2v d = {tpk[cb][0], tpk[cb][1]};
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(twr[cb]), "v"(d), "i"(pb * 4096) : "memory");
+        }
+    };
+    // MODE 2: the 1x1 of T block q (16 pixels x this wavefront's 16 output channels), register set z: fragment reads, MFMAs, epilogue
+    auto g2_read = [&](int z, int q, int s2) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(tf[z][s2]) : "v"(trb ^ (unsigned)(64 * s2)), "i"(q * 4096) : "memory");
+    };
+    auto g2_mfma = [&](int z, int s2) {
+        const acc_t c0 = s2 == 0 ? acc_t{0.f, 0.f, 0.f, 0.f} : acc2[z];
+        acc2[z] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2fr[s2], tf[z][s2], c0, 0, 0, 0);
+    };
+    auto g2_epi = [&](int z, int q, int j, char *obase) {      // j = 0..13: the values; 14: the 8-byte store
+        if (j < 14) epi14(j, acc2[z], b2v, ov, ou, opk);
+        else if (j == 14) *reinterpret_cast<uint2v *>(obase + (o_lane + (unsigned)(q * 8 * a.Cp_out * 2))) = uint2v{opk[0], opk[1]};
+    };
+    // micro-op k of main block blk (MODE 2): the T-write of block blk - 1, the 1x1 of the other half's block, and in the last block the reads
+    // of the 1x1 that has no block of its own (T block 6)
+    auto side2 = [&](int blk, int k) {
+        if (blk != 0 && blk != H0) drain2(blk - 1, k);
+        const bool has = blk < H0 ? blk < NBLK - H0 : true;
+        const int q = blk < H0 ? H0 + blk : blk - H0;         // T block 7 + blk of the previous tile (first half), blk - 7 of this tile (second half)
+        if (has) {
+            if (k < 4) g2_read(0, q, k);
+            if (k >= 38 && k < 53) g2_epi(0, q, k - 38, blk < H0 ? o_prev : o_cur);
+        }
+        if (blk == NBLK - 1) {
+            if (k == 19) g2_read(1, H0 - 1, 0);
+            if (k == 34) g2_read(1, H0 - 1, 1);
+            if (k == 35) g2_read(1, H0 - 1, 2);
+            if (k == 37) g2_read(1, H0 - 1, 3);
+        }
+    };
+    auto side1 = [&](int blk, int k, int ti) {
+        if (blk > 0) drain1(blk - 1, k);
+        else {
+            // the pooled row of tile ti - 1: 52 pixels x 16 pieces of 16 bytes over 256 threads (the fourth round is wavefront 0's;
+            // the others repeat piece 831 - same bytes, no branch): LDS reads at positions 0..3, stores at 18..21
+            const unsigned cprev = xs_lds + ((ti & 1) ? 0u : kCtBytes);
+            if (k < 4) {
+                const int piece = min(tid + k * 256, NBLK * 4 * 16 - 1), px = piece >> 4, ck = piece & 15;
+                asm volatile("ds_read_b128 %0, %1" : "=v"(pst[k]) : "v"(cprev + (unsigned)((px * kCtP + ck * 8) * 2)) : "memory");
+            } else if (k >= 18 && k < 22) {
+                const int piece = min(tid + (k - 18) * 256, NBLK * 4 * 16 - 1), px = piece >> 4, ck = piece & 15;
+                *reinterpret_cast<half8_t *>(o_prev + (size_t)((px * a.Cp_out + ck * 8) * 2)) = pst[k - 18];
+            }
+        }
+    };
+
+    {   // first tile
+        fill_base = (tile_item(0) - WP) * 128;
+#pragma unroll
+        for (int it = 0; it < kFill; ++it) fill_piece(0, it);
+    }
+
+    for (int ti = 0; ti < my_n; ++ti) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                         // tile ti is staged; everybody has left tile ti - 1 (its input buffer, its T / pooled tile are complete)
+        // No side work is conditional.  After the last tile the "next" tile staged is this one again (into the idle buffer); before
+        // the first, the "previous" tile's output goes where THIS tile's will: garbage (from LDS nobody has written) that the same
+        // lanes overwrite with the real values later - one thread's stores to one address keep their order.
+        {
+            const int item = tile_item(ti);
+            if constexpr (MODE == 2) {
+                char *oc = reinterpret_cast<char *>(out) + (size_t)item * a.Cp_out * 2;
+                o_prev = ti > 0 ? o_cur : oc;
+                o_cur = oc;
+            } else if (ti == 0) {
+                const int t = t_first, b = t / HH, oy = t - b * HH;
+                o_prev = reinterpret_cast<char *>(out) + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp) * a.Cp_out * 2 + (size_t)a.out_ch_off * 2;
+            }
+            fill_base = (tile_item(ti + 1 < my_n ? ti + 1 : ti) - WP) * 128;
+        }
+        const unsigned boff = (ti & 1) ? kBufBytes : 0u;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) ecur[tap] = erel[tap] + boff;
+        if constexpr (MODE == 1) {
+            ct_cur[0] = ctw[0] + ((ti & 1) ? kCtBytes : 0u);
+            ct_cur[1] = ctw[1] + ((ti & 1) ? kCtBytes : 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < PD; ++i) issue_a(0, i);
+
+#pragma clang loop unroll(full)
+        for (int g = 0; g < NG; ++g) {
+            if (MODE == 2 && g == H0 * 3) {      // the first half's last block, then the barrier between the halves (LDS only: the next tile's fill stays in flight)
+#pragma unroll
+                for (int k = 0; k < 54; ++k) drain2(H0 - 1, k);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            }
+#if !(Y2_RWB_ABL & 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // group g's fragments (issued during group g - 1) and every other LDS access of that group have landed
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PD; ++i) {
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    const int F = g * PD + i, blk = F / 18, s = F % 18, m = 2 * s + cb, qs = 2 * i + cb;
+                    const acc_t c0 = s == 0 ? acc_t{0.f, 0.f, 0.f, 0.f} : acc[blk & 1][cb];
+                    if constexpr (MODE == 1) acc[blk & 1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[g & 1][i], bfr[s][cb], c0, 0, 0, 0);
+                    else acc[blk & 1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bfr[s][cb], fr[g & 1][i], c0, 0, 0, 0);
+                    if (qs < PD / 2) {                                  // the next group's fragments: two reads in each of the first three slots
+                        if (g + 1 < NG) { issue_a(g + 1, 2 * qs); issue_a(g + 1, 2 * qs + 1); }
+                    } else {
+                        const int k0 = 2 * ((m / 12) * 9 + qs - PD / 2);        // this slot's two micro-op positions
+#if !(Y2_RWB_ABL & 4)
+                        if constexpr (MODE == 1) { side1(blk, k0, ti); side1(blk, k0 + 1, ti); }
+                        else { side2(blk, k0); side2(blk, k0 + 1); }
+#endif
+                    }
+                    if constexpr (MODE == 2) {
+#if !(Y2_RWB_ABL & 4)
+                        // the 1x1's MFMAs ride behind main MFMAs of the block's second group (its fragments were read in the first)
+                        if ((blk < H0 ? blk < NBLK - H0 : true) && m >= 14 && m <= 23 && (m - 14) % 3 == 0) g2_mfma(0, (m - 14) / 3);
+                        if (blk == NBLK - 1 && (m == 26 || m == 30 || m == 34)) g2_mfma(1, (m - 26) / 4);
+#endif
+                    }
+#if !(Y2_RWB_ABL & 2)
+                    if (blk < 4 && m >= 20 && m < 24 && 4 * blk + (m - 20) < kFill) fill_piece(ti + 1, 4 * blk + (m - 20));
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // the tile's last block (nothing left to hide it behind)
+        if constexpr (MODE == 1) {
+#pragma unroll
+            for (int k = 0; k < 20; ++k) drain1(NBLK - 1, k);
+            {   // the pooled row of THIS tile is stored during the next tile (or after the loop): remember where it goes
+                const int t = t_first + ti * S, b = t / HH, oy = t - b * HH;
+                o_prev = reinterpret_cast<char *>(out) + ((size_t)kLead + (size_t)b * a.oPL + (size_t)(oy + 1) * a.oWp) * a.Cp_out * 2 + (size_t)a.out_ch_off * 2;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 54; ++k) drain2(NBLK - 1, k);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the fourth fragment of T block 6
+            g2_mfma(1, 3);
+#pragma unroll
+            for (int j = 0; j < 15; ++j) g2_epi(1, H0 - 1, j, o_cur);
+        }
+    }
+
+    // ---- after the last tile: its pooled row (MODE 1) / the 1x1 of its second half (MODE 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (MODE == 1) {
+        const _Float16 *Ct = Xs + (size_t)((my_n - 1) & 1) * (NBLK * 4) * kCtP;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int piece = tid + it * 256, px = piece >> 4, ck = piece & 15;
+            if (piece < NBLK * 4 * 16)
+                *reinterpret_cast<half8_t *>(o_prev + (size_t)((px * a.Cp_out + ck * 8) * 2)) = *reinterpret_cast<const half8_t *>(Ct + (size_t)px * kCtP + ck * 8);
+        }
+    } else {
+#pragma unroll
+        for (int q = H0; q < NBLK; ++q) {
+            acc_t c2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                const half8_t f = *reinterpret_cast<const half8_t *>(Xs + (size_t)(16 * q + mi) * 128 + (((4 * s2 + kq) ^ mi) * 8));
+                c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(b2fr[s2], f, c2, 0, 0, 0);
+            }
+            const uint2v d = {pack2(leaky(c2[0] + b2v[0]), leaky(c2[1] + b2v[1])), pack2(leaky(c2[2] + b2v[2]), leaky(c2[3] + b2v[3]))};
+            *reinterpret_cast<uint2v *>(o_cur + (o_lane + (unsigned)(q * 8 * a.Cp_out * 2))) = d;
+        }
+    }
+}
+
 // ---- 1x1 layers: persistent workgroups over a ring of staged K-steps --------------------------
 // A 1x1 layer is a plain GEMM [pixels x Cin] x [Cin x Cout] with 2 (layer 5) to 16 (layers 19/21/30) K-steps of 64
 // channels per tile: in the one-tile-per-workgroup kernels above its time is the per-tile set-up, the prologue fill

@@ -29,7 +29,7 @@ struct F16Switches {
     int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
     bool verbose = false;
     int skip = 0;             // diagnostic: see Y2Options::f16_skip
-    bool no_fuse1x1 = false, no_rw = false;
+    bool no_fuse1x1 = false, no_rw = false, no_rwb = false;
     static F16Switches from_options(const Y2Options &o)   // the context's option set (y2_internal.hpp), latched at weight load
     {
         F16Switches s;
@@ -38,7 +38,7 @@ struct F16Switches {
         s.no_halo = o.f16_no_halo; s.no_persist = o.f16_no_persist; s.persist_all = o.f16_persist_all;
         s.ring_all = o.f16_ring_all; s.no_ring = o.f16_no_ring; s.no_c32 = o.f16_no_c32;
         s.m16 = o.f16_m16; s.w8 = o.f16_w8; s.no_wide = o.f16_no_wide;
-        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw;
+        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_rwb = o.f16_no_rwb;
         s.stamp_layer = o.stamp_layer;
         s.verbose = o.verbose;
         s.skip = o.f16_skip;
@@ -237,6 +237,8 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rwb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rwb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
@@ -310,6 +312,7 @@ template <int BN, int NB, int NW, int TS, bool SP = false, bool F1 = false>
 Y2_LAUNCHER(L_halo, hipLaunchKernelGGL((k_conv_f16_halo<BN, NB, NW, TS, SP, F1>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.lt_rows, s.w2, s.bias2))
 template <int MODE> Y2_LAUNCHER(L_rw, hipLaunchKernelGGL((k_conv_f16_rw<13, MODE>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.w2, s.bias2, s.a,
                                                        s.lt_rows, s.T))
+template <int MODE> Y2_LAUNCHER(L_rwb, hipLaunchKernelGGL((k_conv_f16_rwb<MODE>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.w2, s.bias2, s.a, s.T))
 Y2_LAUNCHER(L_maxpool_split, hipLaunchKernelGGL(k_maxpool2_split, s.grid, s.block, 0, st, s.in, s.out, s.oPS, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
 Y2_LAUNCHER(L_reorg_split, hipLaunchKernelGGL(k_reorg_split, s.grid, s.block, 0, st, s.in, s.out, s.B, s.iPS, s.iCp, s.iWp, s.iPL, s.oPS, s.oCp, s.oWp, s.oPL))
 Y2_LAUNCHER(L_maxpool, hipLaunchKernelGGL(k_maxpool2_f16, s.grid, s.block, 0, st, s.in, s.out, s.oCp, s.B, s.OH, s.OW, s.iWp, s.iPL, s.oWp, s.oPL))
@@ -423,6 +426,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                 const int rounds = (s.T + 255) / 256;
                 s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8)))); s.block = dim3(256);
                 const int n_stage = (2 * l.w + 2 * (l.w + 1) + 7) / 8;
+                const bool rwb_ok = !sw.no_rwb && l.leaky && a.n_store == 128;   // k_conv_f16_rwb: leaky layers, every channel stored
                 if (pool_here) {
                     const HT &tp = c->h_out[i + 1];
                     a.pool = 1; a.oWp = tp.Wp; a.oPL = tp.PL; a.npool = B * tp.H * tp.W;
@@ -431,6 +435,11 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                     s.lt_rows = n_stage * 8;
                     s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024 + 2 * (26 * 16 / 4 / 2) * 136 * 2);   // two input tiles + zero region + two pooled tiles
                     s.kernel = "k_conv_f16_rw<pool>"; s.launch = L_rw<1>; s.store = FS_POOL_ONLY;
+                    if (rwb_ok) {       // the epilogue inside the MFMA stream (k_conv_f16_rwb)
+                        s.lt_rows = 432;
+                        s.lds = (unsigned)(2 * 432 * 128 + 2 * 52 * 136 * 2);
+                        s.kernel = "k_conv_f16_rwb<pool>"; s.launch = L_rwb<1>;
+                    }
                 } else if (fuse1) {
                     const HT &t2 = c->h_out[i + 1];
                     a.Cp_out = t2.Cp; a.N = nx.n; a.n_store = round_up(nx.n, 32); a.out_ch_off = 0;
@@ -440,6 +449,11 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                     s.lt_rows = std::max(n_stage, ((13 * 16 * 136 * 2 + 127) / 128 + 7) / 8) * 8;   // the 208 x 136-half intermediate tile must fit an input buffer
                     s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024);
                     s.kernel = "k_conv_f16_rw<+1x1>"; s.launch = L_rw<2>; s.store = FS_FULL;
+                    if (rwb_ok && nx.leaky && t2.Cp == 64) {
+                        s.lt_rows = 432;
+                        s.lds = (unsigned)(2 * 432 * 128 + 208 * 256);        // = 160 KB: the whole LDS of a CU
+                        s.kernel = "k_conv_f16_rwb<+1x1>"; s.launch = L_rwb<2>;
+                    }
                 } else {
                     s.lt_rows = n_stage * 8;
                     s.lds = (unsigned)(2 * s.lt_rows * 128 + 13 * 1024);
