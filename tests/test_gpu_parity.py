@@ -606,7 +606,7 @@ def test_fp16_mfma_path_vs_fp32_reference():
     assert np.array_equal(single[0], region[2])
     # the launch table (built once per batch; the YOLO2_F16_* switches are latched when the weights are loaded)
     kern = ctx.fp16_layer_kernels()
-    assert kern[0] == "k_conv0_pool_mfma" and kern[2] == "k_conv_f16_c32_pool" and kern[30].startswith("k_gemm1_f16_p")
+    assert kern[0] == "k_conv0_pool_mfma" and kern[2] == "k_conv_f16_rwc" and kern[30].startswith("k_gemm1_f16_p")
     assert kern[4] == "k_conv_f16_rwb<+1x1>" and 5 not in kern and kern[6] == "k_conv_f16_rwb<pool>" and kern[22].startswith("k_conv_f16_halo<256")
     assert kern[8] == "k_conv_f16_halo<256,2,16>+1x1" and 9 not in kern, "layer 9 (1x1) runs inside layer 8's launch"
     assert 1 not in kern and 3 not in kern, "pools fused into the convs before them must have no launch of their own"
@@ -615,7 +615,7 @@ def test_fp16_mfma_path_vs_fp32_reference():
 
 @pytest.mark.parametrize("env", ["YOLO2_F16_NO_HALO", "YOLO2_F16_NO_WIDE", "YOLO2_F16_NO_MFMA0", "YOLO2_F16_NO_GLDS", "YOLO2_F16_NO_POOLFUSE", "YOLO2_F16_W8",
                                  "YOLO2_F16_NO_PERSIST", "YOLO2_F16_PERSIST_ALL", "YOLO2_F16_M16", "YOLO2_F16_RING_ALL", "YOLO2_F16_NO_RING", "YOLO2_F16_NO_C32",
-                                 "YOLO2_F16_NO_RW", "YOLO2_F16_NO_RWB", "YOLO2_F16_NO_FUSE1X1"])
+                                 "YOLO2_F16_NO_RW", "YOLO2_F16_NO_RWB", "YOLO2_F16_NO_RWC", "YOLO2_F16_NO_FUSE1X1"])
 def test_fp16_kernel_variants_agree(env, monkeypatch):
     """Every fp16 conv kernel family against the fp32 oracle on a ragged batch (5 frames: partial
     256-pixel tiles on every layer), and against the default selection: the halo-tile kernel vs the

@@ -1886,6 +1886,226 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
     }
 }
 
+// ---- k_conv_f16_rwc: layer 2 (32 -> 64 channels at 208 x 208, + its 2x2 pool) with the weights in registers ---------------------
+// The layer's whole weight set - 64 channels x 9 taps x 32 input channels = 36 B fragments of v_mfma_f32_16x16x32_f16 - fits the
+// registers of ONE wavefront, so here EVERY wavefront holds all of it and the four wavefronts of a workgroup (one per SIMD) split the
+// PIXELS of a tile: a tile is two image rows = 26 blocks of 16 pixels (pool-window order m = 4 w + 2 dy + dx as in k_conv_f16_rw);
+// wavefront w takes blocks 6 w .. 6 w + 5 whole (9 fragment reads, 36 MFMAs each) and HALF of block 24 + (w >> 1) - two of the four
+// channel blocks, 18 MFMAs: 234 MFMAs per wavefront and tile, the same for all four.  (The channel blocks are numbered per wavefront,
+// register block i = channel block (i + 2 (w & 1)) & 3, so that the half block is always register blocks 0 and 1.)  An A fragment
+// feeds four MFMAs and is read by one wavefront only: 252 ds_read_b128 per tile where k_conv_f16_rw needs 936.
+//   * Input: a workgroup walks a RUN of consecutive row pairs of one image and keeps a RING of eight image rows in LDS (row = 212
+//     items of 64 bytes: x = -1 .. 210, the layout's zero columns included - no masks; pitch 212 with the key {row bit 2 -> slot
+//     bit 1} makes the fragment reads conflict-free, brute-forced like k_conv_f16_rwb's).  Tile t reads ring rows 2 t .. 2 t + 3 and
+//     stages rows 2 t + 6, 2 t + 7 - two rows per tile instead of four, two tiles ahead (a fill has a whole tile to land).
+//   * ONE barrier per tile, in the MIDDLE of it (after three blocks): what was requested before the previous barrier is complete
+//     and visible after this one, so the fragment reads run on across tile boundaries (block 0 of tile t + 1 is prefetched during
+//     the half block of tile t) and no wavefront ever waits at a tile's start.  Rows requested after barrier t are used from tile
+//     t + 2 on; they overwrite rows 2 t - 2, 2 t - 1, which nobody reads once everybody has arrived at barrier t.
+//   * Epilogue as micro-ops between the MFMAs like k_conv_f16_rwb MODE 1 (max over the four registers = one pool window, bias,
+//     leaky, fp16, 2-byte write into a pooled LDS tile); the pooled row of tile t - 1 is stored after barrier t; three pooled
+//     tiles, so that a tile's writes (from its second block on) can never meet the reads of the tile three before it.
+// Host: W = 208, 32-channel items in, 64-channel items out, leaky, H / 2 divisible by the run length (build_f16_plan).
+__global__ __launch_bounds__(256) void k_conv_f16_rwc(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh, const float *__restrict__ bias,
+                                                       _Float16 *__restrict__ out, const ConvF16Args a, const int run_len, const int n_runs)
+{
+    constexpr int NBLK = 26, WP = 8 * NBLK + 1, LP = 212, PD = 9, NFULL = 6, NGRP = NFULL + 1, RING = 8;
+    constexpr unsigned kRowBytes = LP * 64;                     // one ring row
+    constexpr int kPairPieces = (2 * LP + 15) / 16, kFill = (kPairPieces + 3) / 4;   // 27 pieces of 16 LDS rows per two image rows, 7 per wavefront
+    constexpr int kCtP = 72;                                    // halves per pixel of a pooled tile
+    constexpr unsigned kCtBytes = NBLK * 4 * kCtP * 2;
+    typedef float acc_t __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(1024))) _Float16 smem_h[];
+    _Float16 *As = smem_h;                                      // ring: [8][LP][32]
+    _Float16 *Xs = smem_h + (size_t)RING * LP * 32;             // pooled tiles [3][104][kCtP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wsel = wave & 1;
+    const int mi = lane & 15, kq = lane >> 4;
+    const int dy = (mi >> 1) & 1, dx = mi & 1, pw = mi >> 2;
+    const int rpi = (a.H >> 1) / run_len;                       // runs per image
+
+    // ---- resident weights and epilogue constants
+    half8_t bfr[9][4];
+    float bv[4];
+    int chn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        chn[i] = 16 * ((i + 2 * wsel) & 3) + mi;
+        bv[i] = bias[chn[i]];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) bfr[tap][i] = *reinterpret_cast<const half8_t *>(wh + ((size_t)chn[i] * 9 + tap) * 32 + 8 * kq);
+    }
+    const unsigned as_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)As;
+    const unsigned xs_lds = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) _Float16 *)Xs;
+    // A fragment (tap, block): ring row ((2 t + dy + ty) & 7), LDS row c0 + 8 block of it, c0 = 2 pw + dx + tx; the 16-byte slot is
+    // kq ^ key, key = 2 ((ring row ^ (c0 >> 2)) & 1) - and the ring row's parity is (dy + ty) & 1 whatever t is
+    unsigned cbase[9], ecur[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ty = tap / 3, tx = tap % 3, c0 = 2 * pw + dx + tx, key = 2 * (((dy + ty) ^ (c0 >> 2)) & 1);
+        cbase[tap] = as_lds + (unsigned)(c0 * 64 + ((kq ^ key) * 16) + 6 * wave * 512);
+    }
+    const int ehd = (24 + (wave >> 1) - 6 * wave) * 512;        // from this wavefront's block 0 to its half block
+    unsigned ctw[4], cth[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ctw[i] = xs_lds + (unsigned)(((4 * 6 * wave + kq) * kCtP + chn[i]) * 2);        // pooled pixel 4 block + kq
+#pragma unroll
+    for (int i = 0; i < 2; ++i) cth[i] = xs_lds + (unsigned)(((4 * (24 + (wave >> 1)) + kq) * kCtP + chn[i]) * 2);
+
+    // ---- staging of two image rows (424 LDS rows) as 27 pieces of 16 rows; the last piece starts at row 408 (it repeats eight rows of
+    // the one before rather than run past the pair)
+    int relp[kFill];
+#pragma unroll
+    for (int it = 0; it < kFill; ++it) {
+        const int p = min(wave + 4 * it, kPairPieces - 1), r0 = min(p * 16, 2 * LP - 16), row = r0 + (lane >> 2), ir = row / LP, c = row - ir * LP;
+        relp[it] = (ir * WP + c - 1) * 64 + (((lane & 3) ^ (2 * ((ir ^ (c >> 2)) & 1))) * 16);
+    }
+    const char *abase = reinterpret_cast<const char *>(act);
+    int run_base = 0;                                            // byte offset of item (b, y_start - 1, 0)
+    auto fill_piece = [&](int pair, int it) {                   // rows 2 pair, 2 pair + 1 of the run
+        const int p = min(wave + 4 * it, kPairPieces - 1), r0 = min(p * 16, 2 * LP - 16);
+        lds_dma16(abase, (unsigned)(run_base + pair * (2 * WP * 64) + relp[it]), As + ((size_t)((2 * pair) & 7) * LP + r0) * 32);
+    };
+
+    half8_t fr[2][PD], frh[PD];                  // fragments of the full blocks (two sets) and of the half block
+    acc_t acc[2][4], acch[2];
+    float pm[4], pt[4];
+    unsigned ph[4];
+    half8_t pst[4];
+    char *o_prev = nullptr, *o_this = nullptr;
+    unsigned ct_cur = 0, ct_prev = 0;                            // byte offsets of this / the previous tile's pooled LDS tile
+
+    auto issue_a = [&](int g, int tap) {                        // group g < 6: block 6 wave + g; group 6: the half block
+        if (g < NFULL) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[g & 1][tap]) : "v"(ecur[tap]), "i"(g * 512) : "memory");
+        else asm volatile("ds_read_b128 %0, %1" : "=v"(frh[tap]) : "v"(ecur[tap] + (unsigned)ehd) : "memory");
+    };
+    auto set_ecur = [&](int ti) {
+        const int s0 = 2 * ti + dy;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) ecur[tap] = cbase[tap] + (unsigned)((s0 + tap / 3) & 7) * kRowBytes;
+    };
+    // epilogue micro-ops of one accumulator (register block i): 0..5 values, 6 the LDS write
+    auto epi1 = [&](int j, const acc_t &v, int i, unsigned dst, int imm_blocks) {
+        if (j == 0) pm[i] = fmaxf(fmaxf(v[0], v[1]), v[2]);
+        else if (j == 1) pm[i] = fmaxf(pm[i], v[3]);
+        else if (j == 2) pm[i] = pm[i] + bv[i];
+        else if (j == 3) pt[i] = pm[i] * 0.1f;
+        else if (j == 4) pm[i] = fmaxf(pm[i], pt[i]);            // leaky == (v < 0 ? 0.1 v : v)
+        else if (j == 5) ph[i] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)pm[i]);
+        else asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(dst), "v"(ph[i]), "i"(imm_blocks * 4 * kCtP * 2) : "memory");   // (block index inside this wavefront's six)
+    };
+    // micro-op position k of the drain of full block pj (its accumulators in set pj & 1): 0..23 values, 24..27 writes
+    auto drain_full = [&](int pj, int k, unsigned cto) {
+        if (k < 24) epi1(k % 6, acc[pj & 1][k / 6], k / 6, 0u, 0);
+        else if (k < 28) epi1(6, acc[pj & 1][k - 24], k - 24, ctw[k - 24] + cto, pj);
+    };
+    auto drain_half = [&](int k, unsigned cto) {                // 0..11 values, 12, 13 writes
+        if (k < 12) epi1(k % 6, acch[k / 6], k / 6, 0u, 0);
+        else if (k < 14) epi1(6, acch[k - 12], k - 12, cth[k - 12] + cto, 0);
+    };
+
+    for (int run = blockIdx.x; run < n_runs; run += gridDim.x) {
+        const int b = run / rpi, ys = (run - b * rpi) * 2 * run_len;
+        run_base = (kLead + b * a.PL + ys * WP) * 64;           // item (b, ys - 1, 0)
+        char *orow0 = reinterpret_cast<char *>(out) + ((size_t)kLead + (size_t)b * a.oPL + (size_t)((ys >> 1) + 1) * a.oWp) * a.Cp_out * 2 + (size_t)a.out_ch_off * 2;
+        __syncthreads();                                         // (a further run: everybody has left the previous one)
+#pragma unroll
+        for (int pair = 0; pair < 3; ++pair)
+#pragma unroll
+            for (int it = 0; it < kFill; ++it) fill_piece(pair, it);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        set_ecur(0);
+#pragma unroll
+        for (int tap = 0; tap < PD; ++tap) issue_a(0, tap);
+        o_this = orow0;
+        o_prev = orow0;                                          // (tile -1: garbage that tile 0's own row overwrites later, see k_conv_f16_rwb)
+        ct_cur = 0; ct_prev = 2 * kCtBytes;
+
+        for (int ti = 0; ti < run_len; ++ti) {
+            // pair index staged during this tile: rows 2 ti + 6, 2 ti + 7; past the run's last rows the last pair is staged again
+            const int fpair = min(ti + 3, run_len);
+#pragma clang loop unroll(full)
+            for (int g = 0; g < NGRP; ++g) {
+                if (g == 3) {                                    // the tile's barrier: fills requested during the previous tile have landed for everybody
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                const int ncb = g < NFULL ? 4 : 2;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (i >= ncb) continue;
+                        const int m = ncb * tap + i;
+                        if (g < NFULL) {
+                            const acc_t c0 = tap == 0 ? acc_t{0.f, 0.f, 0.f, 0.f} : acc[g & 1][i];
+                            acc[g & 1][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fr[g & 1][tap], bfr[tap][i], c0, 0, 0, 0);
+                        } else {
+                            const acc_t c0 = tap == 0 ? acc_t{0.f, 0.f, 0.f, 0.f} : acch[i];
+                            acch[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(frh[tap], bfr[tap][i], c0, 0, 0, 0);
+                        }
+                        if (m < 5) {                             // the next group's nine fragments: two per slot
+                            // (group 6 prefetches block 0 of the NEXT tile: ecur was advanced during group 5; after the run's last tile
+                            //  it reads rows nobody will use)
+                            const int ng = g + 1 < NGRP ? g + 1 : 0;
+                            issue_a(ng, 2 * m);
+                            if (2 * m + 1 < PD) issue_a(ng, 2 * m + 1);
+                        } else {
+                            const int k0 = 2 * (m - 5);
+#pragma unroll
+                            for (int k = k0; k < k0 + 2; ++k) {
+                                if (g == 0) {
+                                    // the previous tile's half block, and the last two writes of its sixth block (the half block's 13 free slots hold 26 of its 28 micro-ops)
+                                    if (k < 14) drain_half(k, ct_prev);
+                                    else if (k < 16) drain_full(NFULL - 1, 26 + (k - 14), ct_prev);
+                                } else if (g < NGRP - 1) {
+                                    if (k < 28) drain_full(g - 1, k, ct_cur);
+                                } else {
+                                    if (k < 26) drain_full(NFULL - 1, k, ct_cur);
+                                }
+                                if (g == 3 && k >= 30 && k < 34) {         // the pooled row of tile ti - 1: LDS reads here, stores one block later
+                                    const int piece = min(tid + (k - 30) * 256, NBLK * 4 * 8 - 1), px = piece >> 3, ck = piece & 7;
+                                    asm volatile("ds_read_b128 %0, %1" : "=v"(pst[k - 30]) : "v"(xs_lds + ct_prev + (unsigned)((px * kCtP + ck * 8) * 2)) : "memory");
+                                }
+                                if (g == 4 && k >= 30 && k < 34) {
+                                    const int piece = min(tid + (k - 30) * 256, NBLK * 4 * 8 - 1), px = piece >> 3, ck = piece & 7;
+                                    *reinterpret_cast<half8_t *>(o_prev + (size_t)((px * a.Cp_out + ck * 8) * 2)) = pst[k - 30];
+                                }
+                                if (g == 5 && k == 30) set_ecur(ti + 1);   // (the half block's fragments were requested in this group's first slots)
+                            }
+                        }
+                        if ((g == 3 && m >= 20 && m < 24) || (g == 4 && m >= 20 && m < 23)) fill_piece(fpair, g == 3 ? m - 20 : 4 + (m - 20));
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            o_prev = o_this;
+            o_this += (size_t)a.oWp * a.Cp_out * 2;
+            ct_prev = ct_cur;
+            ct_cur = ct_cur == 2 * kCtBytes ? 0u : ct_cur + kCtBytes;
+        }
+        // ---- after the run's last tile: what the next tile would have hidden
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 14; ++k) drain_half(k, ct_prev);
+#pragma unroll
+        for (int k = 26; k < 28; ++k) drain_full(NFULL - 1, k, ct_prev);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+        {
+            const _Float16 *Ct = Xs + (size_t)(ct_prev / 2);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int piece = tid + it * 256, px = piece >> 3, ck = piece & 7;
+                if (piece < NBLK * 4 * 8)
+                    *reinterpret_cast<half8_t *>(o_prev + (size_t)((px * a.Cp_out + ck * 8) * 2)) = *reinterpret_cast<const half8_t *>(Ct + (size_t)px * kCtP + ck * 8);
+            }
+        }
+    }
+}
+
 // ---- 1x1 layers: persistent workgroups over a ring of staged K-steps --------------------------
 // A 1x1 layer is a plain GEMM [pixels x Cin] x [Cin x Cout] with 2 (layer 5) to 16 (layers 19/21/30) K-steps of 64
 // channels per tile: in the one-tile-per-workgroup kernels above its time is the per-tile set-up, the prologue fill

@@ -29,7 +29,7 @@ struct F16Switches {
     int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
     bool verbose = false;
     int skip = 0;             // diagnostic: see Y2Options::f16_skip
-    bool no_fuse1x1 = false, no_rw = false, no_rwb = false;
+    bool no_fuse1x1 = false, no_rw = false, no_rwb = false, no_rwc = false;
     static F16Switches from_options(const Y2Options &o)   // the context's option set (y2_internal.hpp), latched at weight load
     {
         F16Switches s;
@@ -38,7 +38,7 @@ struct F16Switches {
         s.no_halo = o.f16_no_halo; s.no_persist = o.f16_no_persist; s.persist_all = o.f16_persist_all;
         s.ring_all = o.f16_ring_all; s.no_ring = o.f16_no_ring; s.no_c32 = o.f16_no_c32;
         s.m16 = o.f16_m16; s.w8 = o.f16_w8; s.no_wide = o.f16_no_wide;
-        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_rwb = o.f16_no_rwb;
+        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_rwb = o.f16_no_rwb; s.no_rwc = o.f16_no_rwc;
         s.stamp_layer = o.stamp_layer;
         s.verbose = o.verbose;
         s.skip = o.f16_skip;
@@ -239,6 +239,7 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rw<13, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rwb<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rwb<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_conv_f16_rwc, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
@@ -302,6 +303,7 @@ template <bool SP> Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16
 template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
 Y2_LAUNCHER(L_c32_pool, hipLaunchKernelGGL(k_conv_f16_c32_pool, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.T))
+Y2_LAUNCHER(L_rwc, hipLaunchKernelGGL(k_conv_f16_rwc, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.lt_rows, s.T))
 template <int BN, bool SP = false> Y2_LAUNCHER(L_glds, hipLaunchKernelGGL((k_conv_f16_glds<BN, SP>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
                                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a))
 template <int BN, int BK> Y2_LAUNCHER(L_reg, hipLaunchKernelGGL((k_conv_f16<128, BN, BK>), s.grid, s.block, 0, st, s.in, s.w, s.bias, s.out,
@@ -472,6 +474,19 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
                 if (bn == 64) { s.kernel = "k_gemm1_f16_p<256,64,3>"; s.launch = L_ring<64>; s.block = dim3(256); s.lds = 3 * (256 + 64) * 128; }
                 else { s.kernel = "k_gemm1_f16_p<256,128,3>"; s.launch = L_ring<128>; s.block = dim3(512); s.lds = 3 * (256 + 128) * 128; }
                 if (s.store != FS_REGION) s.store = FS_FULL;
+                done = true;
+            }
+            // the 32-channel layer + its pool with the weights in registers and a ring of image rows in LDS (k_conv_f16_rwc): runs of
+            // 52, 26 or 13 consecutive row pairs per workgroup - the longest that still gives every CU a run
+            if (!done && !split && !sw.no_rwc && fuse_pool && a.Cp_in == 32 && l.size == 3 && l.n == 64 && l.w == 208 && l.h == 208 && l.leaky &&
+                a.Cp_out == 64 && a.n_store == 64 && a.out_ch_off == 0 && ((size_t)kLead + (size_t)B * a.PL + kTail) * 64 < (1ull << 31)) {
+                int run_len = 52;
+                while (run_len > 13 && B * (l.h / 2 / run_len) < 256) run_len /= 2;
+                s.lt_rows = run_len;                       // (the launcher hands it to the kernel)
+                s.T = B * (l.h / 2 / run_len);             // runs
+                s.kernel = "k_conv_f16_rwc"; s.launch = L_rwc; s.store = FS_POOL_ONLY;
+                s.grid = dim3((unsigned)std::min(s.T, 256)); s.block = dim3(256);
+                s.lds = (unsigned)(8 * 212 * 64 + 3 * 104 * 72 * 2);
                 done = true;
             }
             // the 32-channel layer + its pool: 16 x 16 tiles, patch and all nine taps' weights resident in LDS (k_conv_f16_c32_pool)
