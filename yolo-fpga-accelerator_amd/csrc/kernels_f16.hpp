@@ -1558,7 +1558,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_rw(const _Float16 *__restrict_
 // Host: W = 104, 64-channel items in, leaky layers, every channel stored (build_f16_plan).
 #ifndef Y2_RWB_ABL
 #define Y2_RWB_ABL 0        // diagnostic builds of k_conv_f16_rwb (results wrong, only time matters): 1 = no per-group LDS waits, 2 = no staging,
-#endif                      // 4 = no epilogue work between the MFMAs, 8 = no fragment reads
+#endif                      // 4 = no epilogue work between the MFMAs, 8 = no fragment reads; MODE 1: 16 = epilogue arithmetic without its LDS writes, 32 = the writes without the arithmetic, 64 = no pooled-row store
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh, const float *__restrict__ bias,
                                                        _Float16 *__restrict__ out, const _Float16 *__restrict__ wh2, const float *__restrict__ bias2,
@@ -1688,6 +1688,11 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
     // convert; 18 / 19: the 2-byte LDS writes (early in the next group: an LDS access must be old at the wait that ends its group)
     auto drain1 = [&](int pb, int k) {
         const int set = pb & 1;
+#if (Y2_RWB_ABL & 32)
+        if (k < 12) { if (k % 6 == 0) ph[k / 6] = (unsigned)__builtin_bit_cast(unsigned short, (_Float16)acc[set][k / 6][0]); } else
+#elif (Y2_RWB_ABL & 16)
+        if (k >= 12) { if (k == 19) asm volatile("" ::"v"(ph[0]), "v"(ph[1])); } else
+#endif
         if (k < 12) {
             const int cb = k / 6, j = k % 6;
             if (j == 0) pm[cb] = fmaxf(fmaxf(acc[set][cb][0], acc[set][cb][1]), acc[set][cb][2]);
@@ -1752,7 +1757,11 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
     };
     auto side1 = [&](int blk, int k, int ti) {
         if (blk > 0) drain1(blk - 1, k);
+#if (Y2_RWB_ABL & 64)
+        else if (k < 0) {
+#else
         else {
+#endif
             // the pooled row of tile ti - 1: 52 pixels x 16 pieces of 16 bytes over 256 threads (the fourth round is wavefront 0's;
             // the others repeat piece 831 - same bytes, no branch): LDS reads at positions 0..3, stores at 18..21
             const unsigned cprev = xs_lds + ((ti & 1) ? 0u : kCtBytes);
@@ -1824,7 +1833,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
                     } else {
                         const int k0 = 2 * ((m / 12) * 9 + qs - PD / 2);        // this slot's two micro-op positions
 #if !(Y2_RWB_ABL & 4)
-                        if constexpr (MODE == 1) { side1(blk, k0, ti); side1(blk, k0 + 1, ti); }
+                        if constexpr (MODE == 1) { side1(blk, k0, ti); side1(blk, k0 + 1, ti); }   // (one micro-op per slot instead of two: -1.5 %, within what boxes differ by)
                         else { side2(blk, k0); side2(blk, k0 + 1); }
 #endif
                     }
@@ -1837,6 +1846,9 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
                     }
 #if !(Y2_RWB_ABL & 2)
                     if (blk < 4 && m >= 20 && m < 24 && 4 * blk + (m - 20) < kFill) fill_piece(ti + 1, 4 * blk + (m - 20));
+#endif
+#if (Y2_RWB_ABL & 4)
+                    if (m == 35) asm volatile("" ::"v"(acc[blk & 1][0]), "v"(acc[blk & 1][1]));      // (keeps the MFMAs alive without their consumers)
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                 }
