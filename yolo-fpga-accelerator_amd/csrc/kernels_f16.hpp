@@ -92,7 +92,7 @@ __device__ __forceinline__ int flat_of_fast(const ConvF16Args &a, int q)
 #define Y2_C0_ABL 0         // diagnostic builds of k_conv0_pool_mfma: 1 = no global stores, 2 = cache-hot loads, 4 = no gathers / MFMAs / pooling
 #endif
 #ifndef Y2_ABL
-#define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile
+#define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile, 16 = the centre tap's rows for every tap (no per-tap address arithmetic)
 #endif
 constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
 constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
@@ -770,6 +770,10 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
         const int abuf = ci & 1;
         if (ci + 1 < csteps) fill_a(abuf ^ 1, (ci + 1) * BK);   // lands during the nine taps of this chunk
         const _Float16 *At = As + (size_t)abuf * lt_rows * ROWH;
+        // (Not unrolled: with the nine taps written out hipcc hoists their address arithmetic above the chunk loop - 77 spilled registers.
+        //  Per tap-step a wavefront issues ~34 VALU address instructions beside its 16 fragment reads, 2 LDS-DMA pieces and 16 MFMAs; they
+        //  are not what the loop waits for: with the arithmetic hoisted out of the loop - Y2_ABL = 16, wrong results - the 13 x 13,
+        //  26 x 26 and 52 x 52 layers run 1.5-2.5 % faster, no more.)
 #pragma unroll 1
         for (int tap = 0; tap < 9; ++tap, ++step) {
             const bool more = step + NB - 1 < nsteps;
@@ -787,10 +791,18 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
             int arow[MT], asw[MT];
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
+#if (Y2_ABL & 16)
+                arow[t] = lo[t];                 // diagnostic: the centre tap's rows for every tap - the address arithmetic leaves the loop
+#else
                 arow[t] = ((tapmask[t] >> tap) & 1) ? lo[t] + toff : zrow;
+#endif
                 asw[t] = (arow[t] >> 1) & 7;
             }
+#if (Y2_ABL & 16)
+            const _Float16 *Bt = Bs;             // (and one weight buffer)
+#else
             const _Float16 *Bt = Bs + (size_t)cur * BN * ROWH;
+#endif
             half8_t af[TS == 32 ? 2 : 1][MT], bf[TS == 32 ? 2 : 1][NJ];
             auto read_frags = [&](int kk, int set) {
 #pragma unroll
