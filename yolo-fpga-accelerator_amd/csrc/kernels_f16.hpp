@@ -92,7 +92,7 @@ __device__ __forceinline__ int flat_of_fast(const ConvF16Args &a, int q)
 #define Y2_C0_ABL 0         // diagnostic builds of k_conv0_pool_mfma: 1 = no global stores, 2 = cache-hot loads, 4 = no gathers / MFMAs / pooling
 #endif
 #ifndef Y2_ABL
-#define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile, 16 = the centre tap's rows for every tap (no per-tap address arithmetic)
+#define Y2_ABL 0            // diagnostic builds only (tools/ab.sh): 1 = one fragment read per tap, 2 = no weight-tile fills, 4 = a quarter of the MFMAs, 8 = weight-tile fills from one cache-hot tile, 16 = the centre tap's rows for every tap (no per-tap address arithmetic), 32 = one barrier per nine taps
 #endif
 constexpr int kBN = 128;   // LDS rows are BK + 8 halves: conflict-free ds_read_b128 for BK = 32 and 64
 constexpr int kCtRow = 136;  // halves per row of the epilogue staging tile (128 + 8 pad: 16-byte aligned, conflict-light)
@@ -856,9 +856,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_f16_halo(const _Float16 *__res
             }
             // Loads return in order: all but the weight tile issued in THIS step (BG instructions per wave) have
             // landed, i.e. step + 1's weight tile and, in a chunk's first tap, the next chunk's input tile.
+#if (Y2_ABL & 32)
+            if (tap == 8) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }      // diagnostic: one barrier per chunk instead of one per tap
+#else
             if (more && NB == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BG) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+#endif
             cur = cur == NB - 1 ? 0 : cur + 1;
         }
     }
