@@ -1849,7 +1849,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
                     } else {
                         const int k0 = 2 * ((m / 12) * 9 + qs - PD / 2);        // this slot's two micro-op positions
 #if !(Y2_RWB_ABL & 4)
-                        if constexpr (MODE == 1) { side1(blk, k0, ti); side1(blk, k0 + 1, ti); }   // (one micro-op per slot instead of two: -1.5 %, within what boxes differ by)
+                        if constexpr (MODE == 1) { side1(blk, k0, ti); side1(blk, k0 + 1, ti); }   // (one micro-op per slot instead of two, or one fragment read per slot over six slots: -1.5 .. -3 % on layer 6, within what boxes differ by)
                         else { side2(blk, k0); side2(blk, k0 + 1); }
 #endif
                     }
