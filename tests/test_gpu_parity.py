@@ -681,6 +681,25 @@ def test_fp16_lanes_batch64_consistent():
     ctx.close()
 
 
+def test_fp16_run_kernels_with_more_runs_than_workgroups():
+    """k_conv_f16_rwc (layer 2) gives a workgroup a RUN of consecutive row pairs of one image; at 65 frames per lane the run length is 26
+    and there are 260 runs for 256 workgroups, so four workgroups walk two runs (ring re-staged, pooled tiles reused), and the
+    104 x 104 kernels (k_conv_f16_rwb) walk 13 tiles each with an odd tile count in some XCDs.  Every frame must come out exactly as
+    it does in a batch of four (run length 13, one run per workgroup)."""
+    model = synth.SynthModel(seed=1)
+    frames = np.concatenate([synth.frames(310 + k, 1) for k in range(4)] * 33)[:130]    # 130 frames, period 4
+    ctx = hipdrv.Yolo2Hip(0)
+    ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+    small = ctx.run_batch_fp16_host(frames[:4])
+    big = ctx.run_batch_fp16_host(frames)
+    assert ctx.num_lanes_fp16() == 2
+    kern = ctx.fp16_layer_kernels()
+    assert kern[2] == "k_conv_f16_rwc" and kern[6] == "k_conv_f16_rwb<pool>"
+    for k in (0, 1, 2, 3, 31, 64, 65, 66, 128, 129):
+        assert np.array_equal(big[k], small[k % 4]), k
+    ctx.close()
+
+
 def test_fp16_path_errors():
     ctx = hipdrv.Yolo2Hip(0)
     with pytest.raises(hipdrv.Yolo2HipError, match="fp32 weights not loaded"):
