@@ -330,6 +330,38 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     }
 
 
+def fp16_layer_table(kern, solo_ms, Bl):
+    """SURVEY.md 8d for C4 ("MFMA utilisation + HBM GB/s per layer"): per LAUNCH of the fp16 launch table, with the chip to itself, the
+    algorithmic FLOP/s and the algorithmic bytes/s - what the launch has to read and write as the tensors are stored (fp16 items; layer 0
+    reads the fp32 frames, layer 30 writes the fp32 region tensor; a launch that fuses the pool or the 1x1 after it writes that layer's
+    tensor only) - over its hipEvent time.  MFMA-busy per kernel name is the `mfma_busy` object beside it."""
+    out = {}
+    L = net.LAYERS
+    for l in L:
+        ms = float(solo_ms[l.idx])
+        if ms <= 0 or l.idx not in kern or l.type not in (net.CONV, net.MAXPOOL, net.REORG):
+            continue                                       # (a layer fused into the launch before it has no row: its bytes and FLOPs are that launch's)
+        name = kern.get(l.idx, "")
+        last = l                                           # the layer whose tensor the launch writes
+        flops = 0.0
+        wbytes = 0.0
+        if l.type == net.CONV:
+            flops = 2.0 * l.size * l.size * l.c * l.n * l.out_h * l.out_w
+            wbytes = 2.0 * l.size * l.size * l.c * l.n
+            nx = L[l.idx + 1] if l.idx + 1 < len(L) else None
+            if nx is not None and nx.idx not in kern and nx.type in (net.MAXPOOL, net.CONV):
+                last = nx                                  # fused pool / fused 1x1: no launch of its own
+                if nx.type == net.CONV:
+                    flops += 2.0 * nx.c * nx.n * nx.out_h * nx.out_w
+                    wbytes += 2.0 * nx.c * nx.n
+        in_b = l.c * l.h * l.w * (4.0 if l.idx == 0 else 2.0)
+        out_b = last.n * last.out_h * last.out_w * (4.0 if last.idx == 30 else 2.0)
+        byts = (in_b + out_b) * Bl + wbytes
+        out[str(l.idx)] = {"kernel": name, "ms": round(ms, 4), "tflops": round(flops * Bl / (ms * 1e-3) / 1e12, 1),
+                           "gbps": round(byts / (ms * 1e-3) / 1e9, 0)}
+    return out
+
+
 def fp16_error_vs_fp32(model, frame, gpu_region, threads):
     """Max |error| of the fp16 region tensor against the fp32 oracle (bit-exact restatement of the reference's fp32 path)."""
     import orclib
@@ -432,6 +464,7 @@ def sub_fp16_b256(model, dev, steps=10, warmup=3):
     solo = fp16_solo_layer_ms(ctx, frames, region, B // lanes, stream, dev)
     rec = fp16_record(ctx, B, steps, dt, lane_ms, solo_ms=(solo, B // lanes))
     rec["layer_ms_solo_one_lane"] = [round(float(x), 4) for x in solo]
+    rec["layer_solo"] = fp16_layer_table(ctx.fp16_layer_kernels(), solo, B // lanes)
     rec["warmup"] = warmup
     threads = min(16, len(os.sched_getaffinity(0)))
     import orclib
