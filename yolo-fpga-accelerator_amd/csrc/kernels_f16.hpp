@@ -1574,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_conv_f16_rw(const _Float16 *__restrict_
 // Host: W = 104, 64-channel items in, leaky layers, every channel stored (build_f16_plan).
 #ifndef Y2_RWB_ABL
 #define Y2_RWB_ABL 0        // diagnostic builds of k_conv_f16_rwb (results wrong, only time matters): 1 = no per-group LDS waits, 2 = no staging,
-#endif                      // 4 = no epilogue work between the MFMAs, 8 = no fragment reads; MODE 1: 16 = epilogue arithmetic without its LDS writes, 32 = the writes without the arithmetic, 64 = no pooled-row store
+#endif                      // 4 = no epilogue work between the MFMAs, 8 = no fragment reads; MODE 1: 16 = epilogue arithmetic without its LDS writes, 32 = the writes without the arithmetic, 64 = no pooled-row store (bit 4 also strips k_conv_f16_rwc's epilogue work)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict__ act, const _Float16 *__restrict__ wh, const float *__restrict__ bias,
                                                        _Float16 *__restrict__ out, const _Float16 *__restrict__ wh2, const float *__restrict__ bias2,
@@ -1685,6 +1685,11 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
     unsigned ph[2];
     half8_t pst[4];
     char *o_cur = nullptr, *o_prev = nullptr;    // MODE 2: item (b, y0, 0) of the 1x1's tensor for this / the previous tile; MODE 1: pooled row of the previous tile
+#ifdef Y2_STAMPS
+    // diagnostic builds: wavefront 0 of workgroup 0 records the shader clock at the start of every group of its fourth tile (y2_stamps[0 .. NG], tools/rwb_stamps.py)
+    unsigned tstamp[NG + 1];
+    unsigned long long tprev = 0;
+#endif
 
     auto issue_a = [&](int g, int i) {
         const int F = g * PD + i, blk = F / 18, s = F % 18;
@@ -1835,6 +1840,10 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
 #if !(Y2_RWB_ABL & 1)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // group g's fragments (issued during group g - 1) and every other LDS access of that group have landed
 #endif
+#ifdef Y2_STAMPS
+            if (g > 0) tstamp[g - 1] = (unsigned)tprev;
+            tprev = __builtin_amdgcn_s_memtime();                      // (read one group later, behind that group's wait: the counter's return is never waited for on its own)
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < PD; ++i) {
@@ -1870,6 +1879,15 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
                 }
             }
         }
+#ifdef Y2_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tstamp[NG - 1] = (unsigned)tprev;
+        tstamp[NG] = (unsigned)__builtin_amdgcn_s_memtime();
+        if (a.stamp && ti == 3 && blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+            for (int g = 0; g <= NG; ++g) y2_stamps[g] = tstamp[g];
+        }
+#endif
         // the tile's last block (nothing left to hide it behind)
         if constexpr (MODE == 1) {
 #pragma unroll
@@ -2082,8 +2100,13 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwc(const _Float16 *__restrict
                             if (2 * m + 1 < PD) issue_a(ng, 2 * m + 1);
                         } else {
                             const int k0 = 2 * (m - 5);
+#if (Y2_RWB_ABL & 4)
+                            if (m == ncb * 9 - 1) { if (g < NFULL) asm volatile("" ::"v"(acc[g & 1][0]), "v"(acc[g & 1][1]), "v"(acc[g & 1][2]), "v"(acc[g & 1][3])); else asm volatile("" ::"v"(acc[0][0]), "v"(acch[0]), "v"(acch[1])); }
+                            for (int k = k0; k < k0; ++k) {      // diagnostic: no epilogue work between the MFMAs (they are kept alive)
+#else
 #pragma unroll
                             for (int k = k0; k < k0 + 2; ++k) {
+#endif
                                 if (g == 0) {
                                     // the previous tile's half block, and the last two writes of its sixth block (the half block's 13 free slots hold 26 of its 28 micro-ops)
                                     if (k < 14) drain_half(k, ct_prev);
