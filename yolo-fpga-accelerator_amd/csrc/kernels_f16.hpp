@@ -1716,8 +1716,10 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwb(const _Float16 *__restrict
 #endif
         if (k < 12) {
             const int cb = k / 6, j = k % 6;
-            if (j == 0) pm[cb] = fmaxf(fmaxf(acc[set][cb][0], acc[set][cb][1]), acc[set][cb][2]);
-            else if (j == 1) pm[cb] = fmaxf(pm[cb], acc[set][cb][3]);
+            // (the two maxima as instructions: fmaxf() on values the compiler cannot prove canonical - MFMA results - first runs each
+            //  operand through a v_max x, x, which made these two micro-ops five instructions; an MFMA on finite inputs gives no signalling NaN)
+            if (j == 0) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(pm[cb]) : "v"(acc[set][cb][0]), "v"(acc[set][cb][1]), "v"(acc[set][cb][2]));
+            else if (j == 1) asm("v_max_f32 %0, %1, %2" : "=v"(pm[cb]) : "v"(pm[cb]), "v"(acc[set][cb][3]));
             else if (j == 2) pm[cb] = pm[cb] + bv1[cb];
             else if (j == 3) pt[cb] = pm[cb] * 0.1f;
             else if (j == 4) pm[cb] = fmaxf(pm[cb], pt[cb]);         // leaky == (v < 0 ? 0.1 v : v)
@@ -2032,8 +2034,9 @@ __global__ __launch_bounds__(256) void k_conv_f16_rwc(const _Float16 *__restrict
     };
     // epilogue micro-ops of one accumulator (register block i): 0..5 values, 6 the LDS write
     auto epi1 = [&](int j, const acc_t &v, int i, unsigned dst, int imm_blocks) {
-        if (j == 0) pm[i] = fmaxf(fmaxf(v[0], v[1]), v[2]);
-        else if (j == 1) pm[i] = fmaxf(pm[i], v[3]);
+        // (maxima of MFMA results as instructions: see k_conv_f16_rwb's drain1)
+        if (j == 0) asm("v_max3_f32 %0, %1, %2, %3" : "=v"(pm[i]) : "v"(v[0]), "v"(v[1]), "v"(v[2]));
+        else if (j == 1) asm("v_max_f32 %0, %1, %2" : "=v"(pm[i]) : "v"(pm[i]), "v"(v[3]));
         else if (j == 2) pm[i] = pm[i] + bv[i];
         else if (j == 3) pt[i] = pm[i] * 0.1f;
         else if (j == 4) pm[i] = fmaxf(pm[i], pt[i]);            // leaky == (v < 0 ? 0.1 v : v)
