@@ -288,6 +288,27 @@ def fp16_mfma_busy():
             "per_kernel": {k: v["mfma_busy"] for k, v in doc["kernels"].items() if v["mfma_busy"] > 0}}
 
 
+F16_TRAFFIC_FILE = os.path.join("profiles", "r04_f16_traffic.json")
+
+
+def fp16_traffic(kernel, Bl):
+    """HBM-side bytes per launch of `kernel` (a launch-table name) from the PMC passes of tools/f16_traffic.sh, committed under profiles/ with
+    the hash of csrc/kernels_f16.hpp: (bytes, algorithmic bytes of the same launches, source).  None when the file is absent, was taken on
+    other kernels or at another number of frames per launch."""
+    import hashlib
+    try:
+        doc = json.load(open(os.path.join(ROOT, F16_TRAFFIC_FILE)))
+    except (OSError, ValueError):
+        return None, None, f"{F16_TRAFFIC_FILE} not present"
+    h = hashlib.sha256(open(os.path.join(ROOT, "yolo-fpga-accelerator_amd", "csrc", "kernels_f16.hpp"), "rb").read()).hexdigest()[:16]
+    if doc.get("kernels_f16_hash") != h:
+        return None, None, f"{F16_TRAFFIC_FILE} was measured on other kernels ({doc.get('kernels_f16_hash')}): re-run tools/f16_traffic.sh"
+    e = doc.get("algorithmic", {}).get(kernel)
+    if doc.get("frames_per_launch") != Bl or not e or not e.get("hbm_bytes_per_launch"):
+        return None, None, f"{F16_TRAFFIC_FILE} holds no launches of {kernel} at {Bl} frames per launch"
+    return e["hbm_bytes_per_launch"], e["algorithmic_bytes_per_launch"], F16_TRAFFIC_FILE
+
+
 def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     """Roofline objects of the fp16 MFMA path from one timed run: `dt` seconds for `steps` passes over B frames per GPU,
     layer_ms = the library's per-layer hipEvent times of lane 0 (overlapped with the other lane's launches), solo_ms = the same
@@ -306,6 +327,7 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
     if solo_ms is None:                                          # (multi-GPU line: no solo pass; lane 0's overlapped launches x lanes, upper bound)
         halo_ach = halo_launch_ach * lanes
     chip_ach = 2.0 * net.macs_per_frame() * B / (dt / steps) / 1e12
+    traffic, traffic_alg, traffic_src = fp16_traffic("k_conv_f16_halo<256,2,16>", Bl)
     return {
         "value": world * B * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "dtype": "f16",
         "config": {"workload": f"YOLOv2 fp16 416x416 batch={B} per GPU, MFMA implicit-GEMM conv (fp32 accumulate)",
@@ -315,7 +337,9 @@ def fp16_record(ctx, B, steps, dt, layer_ms, world=1, solo_ms=None):
         # - its layers' FLOPs / their hipEvent time; whole_pass = all conv layers (incl. fused pools and fused 1x1 layers)
         "roofline": {"bound": "mfma", "kernel": "k_conv_f16_halo", "launches_per_step": len(halo), "layers": [l.idx for l in halo],
                      "avg_launch_ms": halo_ms / len(halo), "achieved": halo_ach, "peak": MFMA_PEAK_TFLOPS,
-                     "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "unit": "TFLOP/s", "frac": halo_ach / MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, mean over these launches; Infinity-Cache hits included)",
+                     "traffic_source": traffic_src, "algorithmic_bytes_per_launch": traffic_alg,
                      "algorithmic_flops_per_launch": halo_flops / len(halo), "frames_per_launch": Bl,
                      "timing": "solo" if solo_ms is not None else "overlapped_x_lanes",
                      "note": ("achieved = algorithmic FLOPs of one launch / its mean duration with the chip to itself (lanes off, batch = one "

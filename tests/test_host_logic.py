@@ -27,6 +27,17 @@ def test_library_builds_and_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_integration_doc_indexes_every_entry_point():
+    """INTEGRATION.md section E is generated from include/yolo2_hip.h (tools/abi_index.py): current, and it names every export."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "abi_index.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr or r.stdout
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    index = doc[doc.index("<!-- abi-index:begin"):doc.index("<!-- abi-index:end -->")]
+    missing = [name for name in hipdrv.EXPORTS if f"| `{name}` |" not in index and name not in ("yolo2_weight_len", "yolo2_bias_len")]
+    assert not missing, missing
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     L = hipdrv.lib()
     if L.yolo2_hip_device_count() > 0:
