@@ -615,7 +615,7 @@ def test_fp16_mfma_path_vs_fp32_reference():
 
 @pytest.mark.parametrize("env", ["YOLO2_F16_NO_HALO", "YOLO2_F16_NO_WIDE", "YOLO2_F16_NO_MFMA0", "YOLO2_F16_NO_GLDS", "YOLO2_F16_NO_POOLFUSE", "YOLO2_F16_W8",
                                  "YOLO2_F16_NO_PERSIST", "YOLO2_F16_PERSIST_ALL", "YOLO2_F16_M16", "YOLO2_F16_RING_ALL", "YOLO2_F16_NO_RING", "YOLO2_F16_NO_C32",
-                                 "YOLO2_F16_NO_RW", "YOLO2_F16_NO_RWB", "YOLO2_F16_NO_RWC", "YOLO2_F16_NO_FUSE1X1"])
+                                 "YOLO2_F16_NO_RW", "YOLO2_F16_NO_RWB", "YOLO2_F16_NO_RWC", "YOLO2_F16_NO_FUSE1X1", "YOLO2_F16_RING256", "YOLO2_F16_RING_SQ"])
 def test_fp16_kernel_variants_agree(env, monkeypatch):
     """Every fp16 conv kernel family against the fp32 oracle on a ragged batch (5 frames: partial
     256-pixel tiles on every layer), and against the default selection: the halo-tile kernel vs the

@@ -2800,9 +2800,20 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             pv[it] = *reinterpret_cast<const float4 *>(fb + ((size_t)(pel_pk[it] >> 16) * H + min(max(sy, 0), H - 1)) * W + min(max(sx, 0), W - 4));
         }
     };
+    // Which tiles: round k of the grid works on tiles k G .. (k + 1) G - 1, and workgroups are dealt to the 8 XCDs round-robin, so in launch
+    // order the two tiles either side of a tile - whose patches share its first and last 128-byte line of every row - and the tile rows
+    // above and below (two shared image rows) run on OTHER XCDs and each L2 fetches those lines again: the PMC passes of
+    // tools/f16_traffic.sh counted 848 MB read per 128 frames for 266 MB of frames (profiles/r04_f16_traffic.json), and with the 354 MB
+    // of stores that is the fabric's whole rate (6.3 TB/s in 0.19 ms).  XCD x therefore takes the contiguous eighth x G/8 .. of every round:
+    // ten tile rows of one image meet in one L2.  Same tiles, same bits.
     const int G = (int)gridDim.x;
-    if ((int)blockIdx.x < n_tile_total) request((int)blockIdx.x, pvA);
-    if ((int)blockIdx.x + G < n_tile_total) request((int)blockIdx.x + G, pvB);
+#if defined(Y2_C0_NO_XCD)
+    const int wg = (int)blockIdx.x;
+#else
+    const int wg = (G & 7) ? (int)blockIdx.x : ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+#endif
+    if (wg < n_tile_total) request(wg, pvA);
+    if (wg + G < n_tile_total) request(wg + G, pvB);
     auto do_tile = [&](int tile, float4 (&pv)[NIT]) {
         const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
@@ -2858,7 +2869,7 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
                 *reinterpret_cast<const half8_t *>(&otile[pp][ck * 8]);
         }
     };
-    for (int tile = (int)blockIdx.x; tile < n_tile_total; tile += 2 * G) {
+    for (int tile = wg; tile < n_tile_total; tile += 2 * G) {
         do_tile(tile, pvA);
         if (tile + G < n_tile_total) do_tile(tile + G, pvB);
     }

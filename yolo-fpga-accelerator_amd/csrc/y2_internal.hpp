@@ -66,7 +66,7 @@ struct Y2Options {
     int f16_lanes = 2;
     bool f16_no_lanes = false, f16_no_mfma0 = false, f16_no_glds = false, f16_no_poolfuse = false, f16_no_halo = false, f16_no_persist = false,
          f16_persist_all = false, f16_ring_all = false, f16_no_ring = false, f16_no_c32 = false, f16_m16 = false, f16_w8 = false, f16_no_wide = false,
-         f16_no_fuse1x1 = false, f16_no_rw = false, f16_no_rwb = false, f16_no_rwc = false, f16_ring256 = false;
+         f16_no_fuse1x1 = false, f16_no_rw = false, f16_no_rwb = false, f16_no_rwc = false, f16_ring256 = false, f16_ring_sq = false;
     int stamp_layer = -1;
     int f16_skip = 0;             // DIAGNOSTIC (results wrong by construction): bit mask of fp16 launches left out of the table, to measure
                                   // what a launch costs INSIDE the two-lane step: 1 = 1x1 layers 5 and 9, 2 = layer 0, 4 = layers 2/4/6,

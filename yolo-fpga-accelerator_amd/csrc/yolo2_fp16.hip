@@ -29,7 +29,7 @@ struct F16Switches {
     int stamp_layer = -1;     // diagnostic builds (-DY2_STAMPS): the layer whose halo launch records its workgroup timeline
     bool verbose = false;
     int skip = 0;             // diagnostic: see Y2Options::f16_skip
-    bool no_fuse1x1 = false, no_rw = false, no_rwb = false, no_rwc = false, ring256 = false;
+    bool no_fuse1x1 = false, no_rw = false, no_rwb = false, no_rwc = false, ring256 = false, ring_sq = false;
     static F16Switches from_options(const Y2Options &o)   // the context's option set (y2_internal.hpp), latched at weight load
     {
         F16Switches s;
@@ -38,7 +38,7 @@ struct F16Switches {
         s.no_halo = o.f16_no_halo; s.no_persist = o.f16_no_persist; s.persist_all = o.f16_persist_all;
         s.ring_all = o.f16_ring_all; s.no_ring = o.f16_no_ring; s.no_c32 = o.f16_no_c32;
         s.m16 = o.f16_m16; s.w8 = o.f16_w8; s.no_wide = o.f16_no_wide;
-        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_rwb = o.f16_no_rwb; s.no_rwc = o.f16_no_rwc; s.ring256 = o.f16_ring256;
+        s.no_fuse1x1 = o.f16_no_fuse1x1; s.no_rw = o.f16_no_rw; s.no_rwb = o.f16_no_rwb; s.no_rwc = o.f16_no_rwc; s.ring256 = o.f16_ring256; s.ring_sq = o.f16_ring_sq;
         s.stamp_layer = o.stamp_layer;
         s.verbose = o.verbose;
         s.skip = o.f16_skip;
@@ -243,6 +243,7 @@ static int load_fp32_common(yolo2_hip_ctx *c, const void *weights_reorg, size_t 
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 128, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<128, 256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
+    HIP_TRY(hipFuncSetAttribute((const void *)k_gemm1_f16_p<256, 256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), YOLO2_ERROR);
     if (!c->w0f) HIP_TRY(hipMalloc((void **)&c->w0f, (27 * 32 + 32) * sizeof(float)), YOLO2_MMAP_ERROR);
     hipLaunchKernelGGL(k_pack_w0_f32, dim3(4), dim3(256), 0, nullptr, wd, bd, c->w0f, c->w0f + 27 * 32);
     HIP_TRY(hipGetLastError(), YOLO2_ERROR);
@@ -303,6 +304,7 @@ Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block,
 template <bool SP> Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16<SP>, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
 template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
+Y2_LAUNCHER(L_ring_sq, hipLaunchKernelGGL((k_gemm1_f16_p<256, 256, 2>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, (float *)nullptr, s.a, s.T))
 Y2_LAUNCHER(L_ring256, hipLaunchKernelGGL((k_gemm1_f16_p<128, 256, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, (float *)nullptr, s.a, s.T))
 Y2_LAUNCHER(L_c32_pool, hipLaunchKernelGGL(k_conv_f16_c32_pool, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.T))
 Y2_LAUNCHER(L_rwc, hipLaunchKernelGGL(k_conv_f16_rwc, s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out, s.a, s.lt_rows, s.T))
@@ -469,6 +471,17 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             if (split && !bk64) return fail(YOLO2_ERROR, "fp16 plan (split): layer %d has %d-channel items, not a multiple of the 64-channel K-step", i, a.Cp_in);
             // 1x1 layers whose channel count is a multiple of 256 (13, 15: 256; 19, 21: 512): 128 pixels x 256 channels per tile, so that the
             // input - the bytes this HBM-bound layer moves - is read once per 256 output channels instead of once per 128
+            // (experiment f16_ring_sq) the same layers on 256 x 256 tiles, sixteen wavefronts, two 64-KB stages: twice the FLOPs per staged byte of the
+            // 128 x 128 tiles (an LDS-DMA'd byte feeds 128 FLOPs instead of 64), at the price of 338 / 170 tiles for 256 CUs
+            if (!done && !split && sw.ring_sq && l.size == 1 && bk64 && i != 30 && l.n % 256 == 0 && in32 && !sw.no_ring) {
+                a.n_tiles = l.n / 256;
+                s.T = ((a.npix + 255) / 256) * a.n_tiles;
+                const int rounds = (s.T + 255) / 256;
+                s.grid = dim3(std::min(256, std::max(8, round_up((s.T + rounds - 1) / rounds, 8))));
+                s.kernel = "k_gemm1_f16_p<256,256,2>"; s.launch = L_ring_sq; s.block = dim3(1024); s.lds = 2 * (256 + 256) * 128;
+                s.store = FS_FULL;
+                done = true;
+            }
             if (!done && !split && sw.ring256 && l.size == 1 && bk64 && i != 30 && l.n % 256 == 0 && in32 && !sw.no_ring) {
                 a.n_tiles = l.n / 256;
                 s.T = ((a.npix + 127) / 128) * a.n_tiles;

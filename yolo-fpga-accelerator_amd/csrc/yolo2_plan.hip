@@ -31,7 +31,7 @@ const FlagOpt kFlags[] = {
     {"f16_no_poolfuse", &Y2Options::f16_no_poolfuse}, {"f16_no_halo", &Y2Options::f16_no_halo}, {"f16_no_persist", &Y2Options::f16_no_persist},
     {"f16_persist_all", &Y2Options::f16_persist_all}, {"f16_ring_all", &Y2Options::f16_ring_all}, {"f16_no_ring", &Y2Options::f16_no_ring},
     {"f16_no_c32", &Y2Options::f16_no_c32}, {"f16_m16", &Y2Options::f16_m16}, {"f16_w8", &Y2Options::f16_w8}, {"f16_no_wide", &Y2Options::f16_no_wide},
-    {"f16_no_fuse1x1", &Y2Options::f16_no_fuse1x1}, {"f16_no_rw", &Y2Options::f16_no_rw}, {"f16_no_rwb", &Y2Options::f16_no_rwb}, {"f16_no_rwc", &Y2Options::f16_no_rwc}, {"f16_ring256", &Y2Options::f16_ring256},
+    {"f16_no_fuse1x1", &Y2Options::f16_no_fuse1x1}, {"f16_no_rw", &Y2Options::f16_no_rw}, {"f16_no_rwb", &Y2Options::f16_no_rwb}, {"f16_no_rwc", &Y2Options::f16_no_rwc}, {"f16_ring256", &Y2Options::f16_ring256}, {"f16_ring_sq", &Y2Options::f16_ring_sq},
 };
 const IntOpt kInts[] = {
     {"autotune", &Y2Options::autotune, -1, 1}, {"lanes", &Y2Options::lanes, 0, 8}, {"lane_priority", &Y2Options::lane_priority, 0, 1},
