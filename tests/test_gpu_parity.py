@@ -1249,7 +1249,7 @@ def test_f32tol_mfma_path_every_box_within_1e_3_of_the_fp32_reference():
     single = ctx.run_batch_f32tol_host(frames[3:4])
     assert np.array_equal(single[0], region[3])
     kern = [ctx.f32tol_layer_kernel(i) for i in range(32)]
-    assert kern[0] == "k_conv0_pool_f16<split>" and kern[2] == "k_conv_f16_glds<64,split>" and kern[4].startswith("k_conv_f16_halo_p") and kern[4].endswith("split>")
+    assert kern[0] == "k_conv0_pool_mfma<split>" and kern[2] == "k_conv_f16_glds<64,split>" and kern[4].startswith("k_conv_f16_halo_p") and kern[4].endswith("split>")
     assert kern[22].startswith("k_conv_f16_halo<256") and kern[22].endswith("split>") and kern[30].startswith("k_gemm1_f16_p")
     assert kern[11] == "k_maxpool2_split" and kern[27] == "k_reorg_split" and kern[1] == "" and kern[3] == "" and kern[7] == ""
     # the plain fp16 path on the same context is untouched by the twin (and misses the tolerance, which is why the twin exists)
@@ -1264,6 +1264,29 @@ def test_f32tol_mfma_path_every_box_within_1e_3_of_the_fp32_reference():
     for k in (0, 1, 33, 63):
         assert np.array_equal(rb[k], region[k % 5]), k
     ctx.close()
+
+
+def test_f32tol_layer0_on_mfma_agrees_with_its_fp32_valu_form(monkeypatch):
+    """Layer 0 of the fp32-tolerance pass runs on the matrix cores with (hi, lo) pairs (k_conv0_pool_mfma<split>, three MFMAs per
+    product); option f16_no_mfma0 restores the fp32 VALU form (k_conv0_pool_f16<split>).  Both inside the tolerance against the fp32
+    oracle on a ragged batch (3 frames), and within 1e-4 of each other on the +-4.7 region tensor (different summation orders)."""
+    model = synth.SynthModel(seed=1)
+    frames = synth.frames(21, 3)
+    orclib.oracle().orc_set_threads(16)
+    refs = [orclib.forward_f32(model, frames[k]).reshape(425, 13, 13) for k in (0, 2)]
+    outs = {}
+    for variant, kernel in ((None, "k_conv0_pool_mfma<split>"), ("YOLO2_F16_NO_MFMA0", "k_conv0_pool_f16<split>")):
+        if variant:
+            monkeypatch.setenv(variant, "1")
+        ctx = hipdrv.Yolo2Hip(0)
+        ctx.load_weights_fp32(model.weights_f32(), model.bias_f32())
+        outs[variant] = ctx.run_batch_f32tol_host(frames)
+        assert ctx.f32tol_layer_kernel(0) == kernel
+        ctx.close()
+        for k, ref in zip((0, 2), refs):
+            assert np.abs(outs[variant][k] - ref).max() <= 1e-3, (variant, k)
+    assert np.abs(outs[None] - outs["YOLO2_F16_NO_MFMA0"]).max() <= 1e-4
+    assert not np.array_equal(outs[None], outs["YOLO2_F16_NO_MFMA0"]), "the toggle did not change layer 0's kernel"
 
 
 @pytest.mark.parametrize("qset", ["std", "varq"])

@@ -60,7 +60,7 @@ for i, name in kernels.items():
 # launch-table name (fp16_b256.config.kernels) -> the profiler's name of the instantiation
 PROF = {"k_conv_f16_halo<256,2,16>": "y2::k_conv_f16_halo<256,2,16,32,false,false>", "k_conv_f16_halo<256,2,16>+1x1": "y2::k_conv_f16_halo<256,2,16,32,false,true>",
         "k_conv_f16_rwb<+1x1>": "y2::k_conv_f16_rwb<2>", "k_conv_f16_rwb<pool>": "y2::k_conv_f16_rwb<1>", "k_conv_f16_glds<128>": "y2::k_conv_f16_glds<128,false>",
-        "k_conv_f16_glds<64>": "y2::k_conv_f16_glds<64,false>"}
+        "k_conv_f16_glds<64>": "y2::k_conv_f16_glds<64,false>", "k_conv0_pool_mfma": "y2::k_conv0_pool_mfma<false>"}
 algo = {}
 for name, v in alg.items():
     pk = PROF.get(name, "y2::" + name)

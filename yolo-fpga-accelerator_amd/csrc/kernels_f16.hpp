@@ -2739,6 +2739,11 @@ __global__ void k_pack_weights_f16(const float *__restrict__ src, _Float16 *__re
 // registers r&3 = 0..3 of ONE lane (C layout: row = (r&3) + 8*(r>>2) + 4*(lane>>5)): the pool is an
 // in-lane max, then bias + leaky (monotonic, so it commutes with the max).
 // w0: [27][32] fp32 (k = c*9 + tap), bias0: [32] fp32; out = layer-1 items of 32 halves.
+// SPLIT (the fp32-tolerance pass, 4.6 of DESIGN.md): frame values and weights as (hi, lo) fp16 pairs - a second patch and a second pair of
+// B fragments -, every product as three MFMAs (hi hi + lo hi + hi lo) into the same fp32 accumulators, the pooled fp32 value split again
+// into the layer-1 item's [hi | lo | hi] parts of 32 channels (items of 128 halves).  Replaces the fp32-VALU form k_conv0_pool_f16<true>
+// there (0.59 ms per 64 frames, 9 % of that pass).
+template <bool SPLIT = false>
 __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict__ frames, const float *__restrict__ w0,
                                                           const float *__restrict__ bias0, _Float16 *__restrict__ out, int H,
                                                           int W, int oWp, int oPL, int n_tile_total)
@@ -2746,21 +2751,24 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
     // Patch = rows ty0-1 .. ty0+16, image columns tx0-4 .. tx0+35 (the tile's 34 plus three on either side so that every piece is
     // a 16-byte aligned float4 in the frame: tx0 is a multiple of 32): column tx0-1+p is stored at index p + PSH of its row.
     constexpr int TR = 16, TC = 32, PR = TR + 2, PCS = 40, PSH = 3, PV = 10;   // patch rows / row stride (halves) / shift / float4 pieces per row
-    __shared__ __attribute__((aligned(16))) _Float16 patch[3 * PR * PCS];
-    __shared__ __attribute__((aligned(16))) _Float16 otile[8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
+    constexpr int PLO = 3 * PR * PCS;                                          // SPLIT: the lo patch follows the hi patch, the lo tile the hi tile
+    __shared__ __attribute__((aligned(16))) _Float16 patch[(SPLIT ? 2 : 1) * 3 * PR * PCS];
+    __shared__ __attribute__((aligned(16))) _Float16 otile[(SPLIT ? 2 : 1) * 8 * 16][40];   // pooled tile [pixel][32 ch + pad]: leaves in 16-byte stores
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W / TC, tiles_y = H / TR;
 
     // B fragments (weights), constant for the whole kernel: lane (n = lane & 31, h = lane >> 5) holds B[16kk + 8h + j][n]
     const int n = lane & 31, h = lane >> 5;
-    half8_t bfrag[2];
+    half8_t bfrag[2], bfragl[SPLIT ? 2 : 1];
     int aoff[2][8];   // patch offset (halves) of A element (kk, j) relative to the pixel's top-left tap
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int k = 16 * kk + 8 * h + j;
-            bfrag[kk][j] = k < 27 ? (_Float16)w0[k * 32 + n] : (_Float16)0.f;
+            const float wv = k < 27 ? w0[k * 32 + n] : 0.f;
+            bfrag[kk][j] = (_Float16)wv;
+            if constexpr (SPLIT) bfragl[kk][j] = (_Float16)(wv - (float)bfrag[kk][j]);
             const int c = k / 9, tap = k - c * 9;
             aoff[kk][j] = k < 27 ? (c * PR + tap / 3) * PCS + tap % 3 + PSH : PSH;
         }
@@ -2827,6 +2835,12 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
                 half4_t hv = {(_Float16)pv[it].x, (_Float16)pv[it].y, (_Float16)pv[it].z, (_Float16)pv[it].w};
                 if (!(rowok && colok)) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
                 *reinterpret_cast<half4_t *>(&patch[pel_off[it]]) = hv;
+                if constexpr (SPLIT) {
+                    half4_t lv = {(_Float16)(pv[it].x - (float)hv[0]), (_Float16)(pv[it].y - (float)hv[1]), (_Float16)(pv[it].z - (float)hv[2]),
+                                  (_Float16)(pv[it].w - (float)hv[3])};
+                    if (!(rowok && colok)) lv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    *reinterpret_cast<half4_t *>(&patch[PLO + pel_off[it]]) = lv;
+                }
             }
         }
         __syncthreads();   // the patch is complete; everybody has stored the previous tile's pooled rows
@@ -2846,17 +2860,41 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
 #pragma unroll
                 for (int j = 0; j < 8; ++j) af[j] = patch[base + aoff[kk][j]];
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfrag[kk], acc, 0, 0, 0);
+                if constexpr (SPLIT) {
+                    half8_t al;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) al[j] = patch[PLO + base + aoff[kk][j]];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bfrag[kk], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bfragl[kk], acc, 0, 0, 0);
+                }
             }
             // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
                 if (v < 0.f) v *= 0.1f;
-                otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
+                if constexpr (SPLIT) {
+                    _Float16 vh, vl;
+                    split_f32(v, vh, vl);
+                    otile[prow * 16 + chalf * 8 + 2 * g + h][n] = vh;
+                    otile[128 + prow * 16 + chalf * 8 + 2 * g + h][n] = vl;
+                } else
+                    otile[prow * 16 + chalf * 8 + 2 * g + h][n] = (_Float16)v;
             }
         }
 #endif
         __syncthreads();   // the pooled tile is complete; nobody reads the patch any more
+        if constexpr (SPLIT) {
+            // items of 128 halves, parts [hi | lo | hi] of 32 channels: 128 pooled pixels x 3 parts x 4 chunks = 1536 16-byte stores, six per thread
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int e = tid + it * 256, pp = e / 12, rest = e - pp * 12, part = rest >> 2, ck = rest & 3;
+                const int oy = ty0 / 2 + (pp >> 4), ox = tx0 / 2 + (pp & 15);
+                *reinterpret_cast<half8_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * 128 + part * 32 + ck * 8) =
+                    *reinterpret_cast<const half8_t *>(&otile[(part == 1 ? 128 : 0) + pp][ck * 8]);
+            }
+            return;
+        }
         // 128 pooled pixels x 4 chunks of 8 channels = 512 16-byte stores, two per thread
 #pragma unroll
         for (int it = 0; it < 2; ++it) {

@@ -300,7 +300,7 @@ static int ensure_f16_batch(yolo2_hip_ctx *c, int B)
         (void)frames; (void)region;                                                                    \
         __VA_ARGS__;                                                                                   \
     }
-Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL, s.T))
+template <bool SP = false> Y2_LAUNCHER(L_conv0_mfma, hipLaunchKernelGGL(k_conv0_pool_mfma<SP>, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, 416, 416, s.oWp, s.oPL, s.T))
 template <bool SP> Y2_LAUNCHER(L_conv0_valu, hipLaunchKernelGGL(k_conv0_pool_f16<SP>, s.grid, s.block, 0, st, frames, s.w0, s.bias, s.out, s.B, 416, 416, s.oWp, s.oPL))
 template <int BN> Y2_LAUNCHER(L_ring, hipLaunchKernelGGL((k_gemm1_f16_p<256, BN, 3>), s.grid, s.block, s.lds, st, s.in, s.w, s.bias, s.out,
                                                             s.store == FS_REGION ? region : (float *)nullptr, s.a, s.T))
@@ -348,11 +348,15 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         s.layer = 0; s.B = B;   // (booked to layer 0; the pool, layer 1, has no launch of its own)
         s.w0 = c->w0f; s.bias = c->w0f + 27 * 32; s.out = g.d; s.oWp = g.Wp; s.oPL = g.PL;
         s.block = dim3(256);
-        if (split) {          // fp32 VALU form, nothing rounded before the pool, (hi, lo) out: 128-halve items
+        if (split && !sw.no_mfma0) {   // the MFMA form on (hi, lo) pairs: three MFMAs per product, (hi, lo) out: 128-halve items
+            s.kernel = "k_conv0_pool_mfma<split>"; s.launch = L_conv0_mfma<true>;
+            s.T = B * (416 / 16) * (416 / 32);
+            s.grid = dim3((unsigned)std::min(s.T, 256 * Y2_CONV0_WGS));
+        } else if (split) {   // fp32 VALU form, nothing rounded before the pool (option f16_no_mfma0)
             s.kernel = "k_conv0_pool_f16<split>"; s.launch = L_conv0_valu<true>;
             s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
         } else if (!sw.no_mfma0) {   // 416 = 26 x 16 = 13 x 32: the tile grid is exact
-            s.kernel = "k_conv0_pool_mfma"; s.launch = L_conv0_mfma;
+            s.kernel = "k_conv0_pool_mfma"; s.launch = L_conv0_mfma<false>;
             s.T = B * (416 / 16) * (416 / 32);
             s.grid = dim3((unsigned)std::min(s.T, 256 * Y2_CONV0_WGS));   // persistent workgroups, Y2_CONV0_WGS per CU
         } else {
@@ -792,8 +796,8 @@ extern "C" int yolo2_hip_run_batch_fp16(yolo2_hip_ctx *c, uint64_t frames_dev, i
 // v_mfma_f32_32x32x16_f16 with fp32 accumulation (the dropped a_lo w_lo term is 2^-22 relative).  No new contraction kernel: an
 // item holds three parts [a_hi | a_lo | a_hi], the weights are packed [w_hi | w_hi | w_lo], and the fp16 kernels contract over
 // the tripled channels as they are; only their epilogues differ (SPLIT instantiations: bias + leaky in fp32, then the (hi, lo)
-// split and three stores; pools take the max of the fp32 values).  Layer 0 runs its fp32 VALU form (k_conv0_pool_f16<true>: fp32
-// frames x fp32 weights).  The region layer's kernel writes fp32 as before.  3x the MFMA work and activation bytes of the fp16 path
+// split and three stores; pools take the max of the fp32 values).  Layer 0 runs k_conv0_pool_mfma<true> (frame values and weights split
+// inside the kernel, three MFMAs per product; its fp32 VALU form k_conv0_pool_f16<true> - fp32 frames x fp32 weights - under f16_no_mfma0).  The region layer's kernel writes fp32 as before.  3x the MFMA work and activation bytes of the fp16 path
 // for ~1e-6 relative error: reference arithmetic hls/core/core_compute.cpp:121-172 is what the result is within tolerance of.
 static int ensure_tol_twin(yolo2_hip_ctx *c)
 {
