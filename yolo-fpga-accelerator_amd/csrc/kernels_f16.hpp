@@ -2619,21 +2619,25 @@ __global__ void k_maxpool2_split(const _Float16 *__restrict__ in, _Float16 *__re
     *reinterpret_cast<half8_t *>(o + 2 * PS) = bh;
 }
 
-// Darknet legacy reorg on split items: part p of the 64-channel input goes to channels [0, 256) of part p of the concat items
+// Darknet legacy reorg on split items: part p of the 64-channel input goes to channels [0, 256) of part p of the concat items.  Like
+// k_reorg_f16 below: one thread per (frame, output pixel, part, PAIR of output channels), consecutive lanes write consecutive 4-byte pieces.
 __global__ void k_reorg_split(const _Float16 *__restrict__ in, _Float16 *__restrict__ out, int B, int iPS, int iCp, int iWp, int iPL,
                               int oPS, int oCp, int oWp, int oPL)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * 256 * 169) return;
-    const int b = t / (256 * 169), o = t - b * (256 * 169);
-    const int k = o / (26 * 416), rem = o - k * (26 * 416), j = rem / 26, i = rem - j * 26;
-    const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));
-    const int sc = sidx / 676, sr = sidx - sc * 676, sy = sr / 26, sx = sr - sy * 26;
-    const int oc = o / 169, orr = o - oc * 169, oy = orr / 13, ox = orr - oy * 13;
-    const _Float16 *src = in + ((size_t)kLead + (size_t)b * iPL + (size_t)(sy + 1) * iWp + sx) * iCp + sc;
-    _Float16 *dst = out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * oCp + oc;
+    if (t >= B * 169 * 3 * 128) return;
+    const int cp = t & 127, q = t >> 7, p = q % 3, r = q / 3, pix = r % 169, b = r / 169;
+    const int oy = pix / 13, ox = pix - oy * 13;
+    half2_t v;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) dst[p * oPS] = src[p * iPS];
+    for (int e = 0; e < 2; ++e) {
+        const int o = (2 * cp + e) * 169 + pix;        // the reference's flat output index [256][13][13]
+        const int k = o / (26 * 416), rem = o - k * (26 * 416), j = rem / 26, i = rem - j * 26;
+        const int sidx = (2 * i + (k & 1)) + 52 * (2 * j + (k >> 1));
+        const int sc = sidx / 676, sr = sidx - sc * 676, sy = sr / 26, sx = sr - sy * 26;
+        v[e] = in[((size_t)kLead + (size_t)b * iPL + (size_t)(sy + 1) * iWp + sx) * iCp + p * iPS + sc];
+    }
+    *reinterpret_cast<half2_t *>(out + ((size_t)kLead + (size_t)b * oPL + (size_t)(oy + 1) * oWp + ox) * oCp + p * oPS + 2 * cp) = v;
 }
 
 // weights_reorg (fp32 stream of one layer) -> wh[N_pad][KK][Cp] halves for the split mode: Cp = three parts of PS channels

@@ -645,7 +645,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
             s.layer = i; s.B = B; s.kernel = "k_reorg_f16"; s.launch = L_reorg;
             s.in = gi.d; s.out = go.d; s.iCp = gi.Cp; s.iWp = gi.Wp; s.iPL = gi.PL; s.oCp = go.Cp; s.oWp = go.Wp; s.oPL = go.PL;
             if (split) { s.kernel = "k_reorg_split"; s.launch = L_reorg_split; s.iPS = part_stride(gi.C); s.oPS = part_stride(go.C); }
-            s.grid = dim3(blocks_for((long)B * (split ? 256 : 128) * 169, 256)); s.block = dim3(256);   // (fp16: one thread per channel pair)
+            s.grid = dim3(blocks_for((long)B * (split ? 3 * 128 : 128) * 169, 256)); s.block = dim3(256);   // one thread per channel pair (and part)
             P.steps.push_back(s);
             cur = &c->h_cat;
             break;
