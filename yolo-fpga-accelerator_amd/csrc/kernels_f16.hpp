@@ -2788,13 +2788,14 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
     // 128-byte line and wrote them with 2-byte LDS stores; with every request aimed at one cache-hot patch - Y2_C0_ABL = 2 - the
     // kernel took 0.160 instead of 0.237 ms per 128 frames: the loads, not the gathers, were what it waited for.)
     constexpr int NPC = 3 * PR * PV, NIT = (NPC + 255) / 256;
-    int pel_off[NIT], pel_pk[NIT];   // LDS offset (halves) of the piece; py | j << 8 | c << 16
+    int pel_off[NIT], pel_pk[NIT], pel_src[NIT];   // LDS offset (halves) of the piece; py | j << 8 | c << 16; its offset (floats) from the patch's first element
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = min(tid + it * 256, NPC - 1);
         const int row = i / PV, j = i - row * PV, c = row / PR, py = row - c * PR;
         pel_pk[it] = py | (j << 8) | (c << 16);
         pel_off[it] = row * PCS + 4 * j;
+        pel_src[it] = (c * H + py) * W + 4 * j;
     }
     // Two tiles' pieces in flight: the set a tile is converted from was requested TWO tiles earlier (one tile ahead left ~0.05 of
     // 0.19 ms per 128 frames waiting for loads: Y2_C0_ABL = 2).
@@ -2806,6 +2807,12 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
         const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
         const float *fb = frames + (size_t)b * 3 * H * W;
+        if (ty0 > 0 && ty0 + TR < H && tx0 > 0 && tx0 + TC < W) {      // an interior tile (wave-uniform): the whole patch is inside the plane, no clamps
+            const float *tb = fb + (size_t)(ty0 - 1) * W + (tx0 - 4);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) pv[it] = *reinterpret_cast<const float4 *>(tb + pel_src[it]);
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 - 4 + 4 * ((pel_pk[it] >> 8) & 255);
@@ -2829,20 +2836,24 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
     auto do_tile = [&](int tile, float4 (&pv)[NIT]) {
         const int b = tile / (tiles_x * tiles_y), tr = tile % (tiles_x * tiles_y);
         const int ty0 = (tr / tiles_x) * TR, tx0 = (tr % tiles_x) * TC;
+        const bool interior = ty0 > 0 && ty0 + TR < H && tx0 > 0 && tx0 + TC < W;   // wave-uniform: nothing of the patch is outside the image
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
             if (i < NPC) {
-                const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 - 4 + 4 * ((pel_pk[it] >> 8) & 255);
-                const bool rowok = sy >= 0 && sy < H, colok = sx >= 0 && sx < W;      // (a piece is wholly inside or wholly outside the image: W % 4 == 0)
+                bool keep = true;
+                if (!interior) {          // (uniform branch: 78 % of the tiles skip the masks)
+                    const int sy = ty0 + (pel_pk[it] & 255) - 1, sx = tx0 - 4 + 4 * ((pel_pk[it] >> 8) & 255);
+                    keep = sy >= 0 && sy < H && sx >= 0 && sx < W;      // (a piece is wholly inside or wholly outside the image: W % 4 == 0)
+                }
                 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
                 half4_t hv = {(_Float16)pv[it].x, (_Float16)pv[it].y, (_Float16)pv[it].z, (_Float16)pv[it].w};
-                if (!(rowok && colok)) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                if (!keep) hv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
                 *reinterpret_cast<half4_t *>(&patch[pel_off[it]]) = hv;
                 if constexpr (SPLIT) {
                     half4_t lv = {(_Float16)(pv[it].x - (float)hv[0]), (_Float16)(pv[it].y - (float)hv[1]), (_Float16)(pv[it].z - (float)hv[2]),
                                   (_Float16)(pv[it].w - (float)hv[3])};
-                    if (!(rowok && colok)) lv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    if (!keep) lv = half4_t{(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
                     *reinterpret_cast<half4_t *>(&patch[PLO + pel_off[it]]) = lv;
                 }
             }
@@ -2875,8 +2886,15 @@ __global__ __launch_bounds__(256) void k_conv0_pool_mfma(const float *__restrict
             // lane holds channel n for pooled columns 2g + h (g = 0..3): registers 4g .. 4g+3 are one pool window
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                float v = fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])) + bv;
-                if (v < 0.f) v *= 0.1f;
+                // (fmaxf() on MFMA results - which the compiler cannot prove canonical - first runs every operand through a v_max x, x: the
+                //  pool's maxima were nine instructions.  Inline-asm maxima as in k_conv_f16_rwb are NOT an option here: they would read the
+                //  accumulators right behind the MFMAs, and the compiler does not see an asm's operands when it places the wait states an MFMA
+                //  result needs - measured: wrong values.  Adding the bias FIRST gives canonical operands - four adds, v_max3, v_max - and the
+                //  same bits, rounding being monotonic; leaky as max(v, 0.1 v) == (v < 0 ? 0.1 v : v).  The kernel issues ~450 VALU
+                //  instructions per tile and wavefront at four wavefronts per SIMD: since its loads stopped being fetched three times over,
+                //  that issue stream is what it runs at.)
+                float v = fmaxf(fmaxf(acc[4 * g] + bv, acc[4 * g + 1] + bv), fmaxf(acc[4 * g + 2] + bv, acc[4 * g + 3] + bv));
+                v = fmaxf(v, v * 0.1f);
                 if constexpr (SPLIT) {
                     _Float16 vh, vl;
                     split_f32(v, vh, vl);
