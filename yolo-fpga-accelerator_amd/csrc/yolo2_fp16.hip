@@ -351,7 +351,7 @@ static int build_f16_plan(yolo2_hip_ctx *c, int B)
         if (split && !sw.no_mfma0) {   // the MFMA form on (hi, lo) pairs: three MFMAs per product, (hi, lo) out: 128-halve items
             s.kernel = "k_conv0_pool_mfma<split>"; s.launch = L_conv0_mfma<true>;
             s.T = B * (416 / 16) * (416 / 32);
-            s.grid = dim3((unsigned)std::min(s.T, 256 * Y2_CONV0_WGS));
+            s.grid = dim3((unsigned)std::min(s.T, 256 * 3));   // 161 registers: three workgroups per CU are resident - a fourth would run behind them
         } else if (split) {   // fp32 VALU form, nothing rounded before the pool (option f16_no_mfma0)
             s.kernel = "k_conv0_pool_f16<split>"; s.launch = L_conv0_valu<true>;
             s.grid = dim3(blocks_for((long)B * g.H * g.W, 256), 2);
