@@ -491,3 +491,65 @@ def test_bench_rank_environment_without_launcher_is_still_accepted():
     e = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="3")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-launch"], env=e, capture_output=True, text=True)
     assert p.returncode == 2 and "must start exactly" in p.stderr
+
+
+def test_fp16_traffic_tool_and_bench_attachment(tmp_path):
+    """tools/f16_traffic.py on synthetic counter files (the shape rocprofv3 --pmc writes): bytes = 2 x FETCH_SIZE + WRITE_SIZE per launch and
+    kernel name, the calibration row on k_maxpool2_f16, algorithmic bytes per launch-table name, the hash of csrc/kernels_f16.hpp; and
+    bench.fp16_traffic() hands the halo kernel's figure to the fp16 record only when hash and frames per launch match."""
+    import csv
+    import json
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from kernel_names import demangle
+    assert demangle("_ZN2y215k_conv_f16_haloILi256ELi2ELi16ELi32ELb0ELb0EEEvPKDF16_S2_") == "y2::k_conv_f16_halo<256,2,16,32,false,false>"
+    assert demangle("_ZN2y214k_maxpool2_f16EPKDF16_PS0_iiiiiii") == "y2::k_maxpool2_f16"
+    assert demangle("void y2::k_conv_i16<3, 1, 4, 2, 1>(int2 const*)") == "y2::k_conv_i16<3, 1, 4, 2, 1>"
+    kernels = {"10": "k_conv_f16_halo<256,2,16>", "11": "k_maxpool2_f16", "17": "k_maxpool2_f16"}
+    line = {"config": {"frames_per_launch": 2, "kernels": kernels}}
+    pool_read = sum(l.c * l.h * l.w * 2 * 2 for l in net.LAYERS if l.idx in (11, 17)) / 2       # bytes one pool launch reads, mean of the two
+    names = {"_ZN2y215k_conv_f16_haloILi256ELi2ELi16ELi32ELb0ELb0EEEvPKDF16_S2_": (6, 3000.0, 500.0),
+             "_ZN2y214k_maxpool2_f16EPKDF16_PS0_iiiiiii": (4, pool_read / 2 / 1024, 100.0)}       # (launches, FETCH_SIZE KB, WRITE_SIZE KB) per launch
+    for k, cnt in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
+        d = tmp_path / cnt / "run"
+        d.mkdir(parents=True)
+        (tmp_path / cnt / "bench.json").write_text("some log line\n" + json.dumps(line) + "\n")
+        with open(d / "1_counter_collection.csv", "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writeheader()
+            i = 0
+            for name, v in names.items():
+                for _ in range(v[0]):
+                    i += 1
+                    w.writerow({"Dispatch_Id": i, "Kernel_Name": name, "Counter_Name": cnt, "Counter_Value": v[1 + k]})
+    out = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "f16_traffic.py"), str(tmp_path), str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    doc = json.loads(out.read_text())
+    halo = doc["kernels"]["y2::k_conv_f16_halo<256,2,16,32,false,false>"]
+    assert halo["launches"] == 6 and halo["read_bytes_per_launch"] == 2 * 3000 * 1024 and halo["write_bytes_per_launch"] == 500 * 1024
+    assert abs(doc["calibration_on_k_maxpool2_f16"]["read_ratio"] - 1.0) < 1e-9 and doc["calibration_on_k_maxpool2_f16"]["layers"] == [11, 17]
+    l10 = net.LAYERS[10]
+    alg = doc["algorithmic"]["k_conv_f16_halo<256,2,16>"]
+    assert alg["layers"] == [10] and alg["hbm_bytes_per_launch"] == halo["hbm_bytes_per_launch"]
+    assert alg["algorithmic_bytes_per_launch"] == (l10.c * l10.h * l10.w + l10.n * l10.out_h * l10.out_w) * 2 * 2 + l10.n * l10.c * 9 * 2 + l10.n * 4
+    # bench.py attaches it only for the tree and the launch size it was measured on
+    sys.path.insert(0, ROOT)
+    import bench
+    saved = bench.F16_TRAFFIC_FILE
+    try:
+        bench.F16_TRAFFIC_FILE = str(out)
+        t, a, src = bench.fp16_traffic("k_conv_f16_halo<256,2,16>", 2)
+        assert t == halo["hbm_bytes_per_launch"] and a == alg["algorithmic_bytes_per_launch"] and src == str(out)
+        assert bench.fp16_traffic("k_conv_f16_halo<256,2,16>", 128)[0] is None          # other frames per launch
+        doc["kernels_f16_hash"] = "0" * 16
+        out.write_text(json.dumps(doc))
+        t, a, src = bench.fp16_traffic("k_conv_f16_halo<256,2,16>", 2)
+        assert t is None and "other kernels" in src
+        bench.F16_TRAFFIC_FILE = str(tmp_path / "absent.json")
+        assert bench.fp16_traffic("k_conv_f16_halo<256,2,16>", 2)[0] is None
+    finally:
+        bench.F16_TRAFFIC_FILE = saved
+    # the committed file belongs to the committed kernels: the default bench line will carry it
+    t, a, src = bench.fp16_traffic("k_conv_f16_halo<256,2,16>", 128)
+    assert t and a and t > a and src == bench.F16_TRAFFIC_FILE, src
